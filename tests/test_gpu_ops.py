@@ -1,0 +1,209 @@
+"""GPU parity: every HIP operator (through the C ABI) against the fp32 CPU oracle on seeded inputs.
+
+Inputs are rounded to fp16 first, so the only differences are fp32 accumulation order and the final
+fp16 rounding of the output: tolerance = 2e-3 relative to the output scale (fp16 has 2^-11 = 4.9e-4
+relative precision).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops_ref as R  # noqa: E402
+from oracle import gcvit_ref  # noqa: E402
+
+
+def _ops():
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ops
+    return ops
+
+
+def h(t):
+    """fp16-rounded fp32 copy (CPU) of t"""
+    return t.to(torch.float16).to(torch.float32)
+
+
+def dev(t):
+    return t.to(torch.float16).cuda().contiguous()
+
+
+def check(report, name, got, ref, tol=2e-3):
+    got = got.float().cpu()
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    rms = ((got - ref) ** 2).mean().sqrt().item()
+    report(f"[ops] {name}: max_abs_err={err:.3e} rms={rms:.3e} ref_absmax={scale:.3e} rel={err / scale:.3e}")
+    assert torch.isfinite(got).all(), name
+    assert err <= tol * scale, f"{name}: err {err} > {tol}*{scale}"
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad(t,b,l,r), groups, act, residual
+    (2, 9, 9, 8, 32, 3, 2, (1, 1, 1, 1), 1, "relu", False),      # stem-like: Cin=8, K=72 (partial k-tile)
+    (2, 12, 10, 32, 64, 3, 1, (1, 1, 1, 1), 1, "relu", False),   # 3x3 same
+    (3, 7, 7, 64, 256, 1, 1, (0, 0, 0, 0), 1, None, True),       # 1x1 + residual
+    (2, 13, 13, 128, 128, 3, 2, (1, 1, 1, 1), 1, "silu", False),  # stride 2 odd size
+    (1, 20, 20, 24, 40, 3, 1, (1, 1, 1, 1), 1, "gelu", False),   # channels not multiples of 32/64
+    (2, 8, 8, 128, 128, 3, 1, (1, 1, 1, 1), 2, "relu", False),   # grouped (NFNet / ResNeSt style)
+    (2, 10, 10, 16, 200, 4, 2, (0, 0, 0, 0), 1, None, False),    # 4x4/2 VALID patchify, Cout not /64
+    (2, 6, 6, 512, 72, 1, 1, (0, 0, 0, 0), 1, "sigmoid", False),  # deep K, narrow N
+    (1, 33, 31, 64, 64, 3, 1, (1, 1, 1, 1), 1, "relu", True),    # M tail (1023 pixels)
+    (2, 9, 9, 64, 64, 5, 1, (2, 2, 2, 2), 1, None, False),       # 5x5
+    (2, 9, 9, 96, 96, 2, 2, (0, 0, 0, 0), 1, None, False),       # 2x2/2 downsample (ConvNeXt)
+    (2, 9, 9, 32, 32, 3, 2, (0, 1, 0, 1), 1, "silu", False),     # TF SAME asymmetric pad (EffNetV1)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:9]))
+def test_conv2d(case, report):
+    ops = _ops()
+    B, H, W, Cin, Cout, k, s, pad, groups, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case[:9]) % (2 ** 31))
+    x = h(torch.randn(B, H, W, Cin, generator=g))
+    w = h(torch.randn(k, k, Cin // groups, Cout, generator=g) / math.sqrt(k * k * Cin / groups))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    ref = R.conv2d(x, w, bias, s, pad, groups)
+    ref = R.act(ref, act)
+    res = None
+    if use_res:
+        res = h(torch.randn(*ref.shape, generator=g))
+        ref = ref + res
+    cw = ops.make_conv_weight(w, bias, groups=groups)
+    got = ops.conv2d(dev(x), cw, stride=s, pad=pad, act=act, residual=None if res is None else dev(res))
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    check(report, f"conv2d {case}", got, ref)
+
+
+def test_conv2d_act_post_and_channel_slices(report):
+    """act applied after the residual; input/outputs addressed as channel slices of wider tensors."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    x = h(torch.randn(2, 8, 8, 64, generator=g))
+    w = h(torch.randn(3, 3, 32, 48, generator=g) / math.sqrt(9 * 32))
+    res = h(torch.randn(2, 8, 8, 48, generator=g))
+    ref = R.act(R.conv2d(x[..., 32:], w, None, 1, (1, 1, 1, 1)) + res, "relu")
+    cw = ops.make_conv_weight(w, None)
+    out = torch.zeros(2, 8, 8, 96, dtype=torch.float16, device="cuda")
+    ops.conv2d(dev(x), cw, pad=(1, 1, 1, 1), act_post="relu", residual=dev(res), out=out, cin_off=32, cout_off=48)
+    torch.cuda.synchronize()
+    check(report, "conv2d slices", out[..., 48:], ref)
+    assert out[..., :48].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("M,K,N", [(256, 64, 16), (1000, 256, 768), (197 * 3, 192, 576), (5, 2048, 8), (4096, 768, 3072)])
+def test_dense(M, K, N, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = h(torch.randn(M, K, generator=g))
+    w = h(torch.randn(K, N, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    res = h(torch.randn(M, N, generator=g))
+    ref = R.act(R.dense(x, w, b), "gelu") + res
+    got = ops.dense(dev(x), ops.make_dense_weight(w, b), act="gelu", residual=dev(res))
+    torch.cuda.synchronize()
+    check(report, f"dense {M}x{K}x{N}", got, ref)
+
+
+@pytest.mark.parametrize("k,s,C,H", [(3, 1, 64, 14), (3, 2, 72, 15), (5, 1, 40, 12), (5, 2, 48, 13), (7, 1, 96, 11)])
+def test_dwconv(k, s, C, H, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(k * 100 + s * 10 + C)
+    x = h(torch.randn(2, H, H + 1, C, generator=g))
+    w = h(torch.randn(k, k, C, 1, generator=g) / k)
+    b = torch.randn(C, generator=g) * 0.1
+    p = k // 2
+    ref = R.act(R.dwconv2d(x, w, b, s, (p, p, p, p)), "gelu")
+    got = ops.dwconv2d(dev(x), dev(w[..., 0]), b.cuda(), k, s, (p, p, p, p), act="gelu")
+    torch.cuda.synchronize()
+    check(report, f"dwconv k{k} s{s} C{C}", got, ref)
+
+
+@pytest.mark.parametrize("C", [64, 96, 128, 192, 256, 384, 512, 768, 1024, 2048])
+def test_layernorm(C, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    x = h(torch.randn(37, C, generator=g) * 3 + 0.5)
+    gamma = torch.randn(C, generator=g) * 0.1 + 1
+    beta = torch.randn(C, generator=g) * 0.1
+    ref = R.layernorm(x, gamma, beta, 1e-5)
+    got = ops.layernorm(dev(x), gamma.cuda(), beta.cuda(), 1e-5)
+    torch.cuda.synchronize()
+    check(report, f"layernorm C{C}", got, ref)
+
+
+def test_pools(report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = h(torch.randn(2, 13, 25, 64, generator=g))
+    got = ops.pool2d(dev(x), 2, 2, (0, 1, 0, 1), ops.POOL_AVG_VALID)
+    check(report, "avgpool same 2x2/2 odd", got, R.avgpool_same(x, 2, 2))
+    x2 = h(torch.randn(2, 14, 14, 32, generator=g)) - 2.0  # mostly negative: zero padding must win the max
+    got = ops.pool2d(dev(x2), 3, 2, (1, 1, 1, 1), ops.POOL_MAX_ZEROPAD)
+    check(report, "maxpool 3x3/2 zero-pad", got, R.maxpool_valid(x2, 3, 2, (1, 1, 1, 1)))
+    got = ops.pool2d(dev(x), 3, 2, (1, 1, 1, 1), ops.POOL_AVG_FULL)
+    check(report, "avgpool 3x3/2 zero-pad count-all", got, R.avgpool_valid(x, 3, 2, (1, 1, 1, 1)))
+    got = ops.global_avgpool(dev(x))
+    check(report, "global_avgpool", got, R.global_avgpool(x))
+
+
+def test_scale_add_act_and_head(report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    x = h(torch.randn(3, 7, 7, 128, generator=g))
+    s = h(torch.rand(3, 128, generator=g))
+    r = h(torch.randn(3, 7, 7, 128, generator=g))
+    got = ops.scale_add_act(dev(x), dev(s), dev(r), "relu")
+    check(report, "scale_add_act", got, torch.relu(x * s[:, None, None, :] + r))
+    w = torch.randn(128, 3, generator=g) / 11
+    b = torch.randn(3, generator=g)
+    got = ops.gap_dense_f32(dev(x), w.t().contiguous().cuda(), b.cuda())
+    check(report, "gap_dense_f32", got, R.dense(R.global_avgpool(x), w, b), tol=1e-5)
+
+
+@pytest.mark.parametrize("ws,heads,nW,global_q", [(7, 2, 3, False), (7, 4, 2, True), (14, 8, 1, False), (14, 8, 2, True),
+                                                  (7, 16, 1, True)])
+def test_window_attention(ws, heads, nW, global_q, report):
+    """vip_window_attn_fwd_f16 vs attention.py:60-80 restated (window partition done by the oracle)."""
+    ops = _ops()
+    B, C, hd = 2, heads * 32, 32
+    Hp = Wp = ws * nW
+    g = torch.Generator().manual_seed(ws * 1000 + heads * 10 + nW)
+    nq = 2 if global_q else 3
+    qkv = h(torch.randn(B, Hp, Wp, nq * C, generator=g))
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5
+    qg = h(torch.randn(B, ws, ws, C, generator=g)) if global_q else None
+    # oracle: window partition -> [B_, N, nq, heads, hd]
+    win = R.window_partition(qkv, ws).reshape(-1, ws * ws, nq, heads, hd).permute(2, 0, 3, 1, 4)
+    B_ = win.shape[1]
+    if global_q:
+        k, v = win[0], win[1]
+        q = torch.repeat_interleave(qg, B_ // B, dim=0).reshape(B_, ws * ws, heads, hd).permute(0, 2, 1, 3)
+    else:
+        q, k, v = win[0], win[1], win[2]
+    o = gcvit_ref.window_attention_core(q, k, v, table, ws, hd ** -0.5)
+    ref = R.window_reverse(o.permute(0, 2, 1, 3).reshape(B_, ws * ws, C), ws, Hp, Wp, C)
+    got = ops.window_attention(dev(qkv), None if qg is None else dev(qg).reshape(B, ws * ws, C), table.cuda(), heads, ws,
+                               hd ** -0.5)
+    torch.cuda.synchronize()
+    check(report, f"window_attn ws{ws} heads{heads} nW{nW} global={global_q}", got, ref, tol=3e-3)
+
+
+def test_window_attention_softmax_spike(report):
+    """One key dominating one query (large logit) must not overflow and must pick that key's value."""
+    ops = _ops()
+    ws, heads, C = 7, 2, 64
+    g = torch.Generator().manual_seed(11)
+    qkv = h(torch.randn(1, 7, 7, 3 * C, generator=g))
+    qkv[0, 3, 3, 0:32] = 12.0          # q of token (3,3), head 0
+    qkv[0, 5, 1, C:C + 32] = 12.0      # k of token (5,1), head 0  -> logit 12*12*32/sqrt(32) = 814
+    table = torch.zeros(169, heads)
+    win = R.window_partition(qkv, ws).reshape(-1, 49, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    o = gcvit_ref.window_attention_core(win[0], win[1], win[2], table, ws, 32 ** -0.5)
+    ref = R.window_reverse(o.permute(0, 2, 1, 3).reshape(1, 49, C), ws, 7, 7, C)
+    got = ops.window_attention(dev(qkv), None, table.cuda(), heads, ws, 32 ** -0.5)
+    torch.cuda.synchronize()
+    check(report, "window_attn spike", got, ref, tol=3e-3)

@@ -1,0 +1,69 @@
+"""ctypes binding of include/vipcup_hip.h.  Loads the in-tree libvipcup_hip.so and fails loudly if it
+is absent (there is deliberately no CPU fallback)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvipcup_hip.so")
+
+_lib = None
+
+
+class VipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mirror of vip_conv_desc (include/vipcup_hip.h)"""
+    _fields_ = [(n, C.c_int) for n in (
+        "B", "H", "W", "Cin", "Cout", "kh", "kw", "sh", "sw", "pt", "pl", "Ho", "Wo", "groups",
+        "ldx", "cin_off", "ldy", "cout_off", "ldr", "res_off", "ldw", "act_pre", "act_post")]
+
+
+class JpegDesc(C.Structure):
+    """mirror of vip_jpeg_desc (include/vipcup_hip.h)"""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ncomp", C.c_int32),
+                ("hsamp", C.c_int32 * 3), ("vsamp", C.c_int32 * 3),
+                ("blocks_w", C.c_int32 * 3), ("blocks_h", C.c_int32 * 3),
+                ("coef_off", C.c_int64 * 3), ("qt", (C.c_uint16 * 64) * 3)]
+
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/vipcup_hip.h declares
+SIGNATURES = {
+    "vip_version": (_i, []),
+    "vip_last_error": (C.c_char_p, []),
+    "vip_conv2d_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
+    "vip_gemm_bias_act_f16": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
+    "vip_dwconv2d_nhwc_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
+    "vip_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "vip_pool2d_nhwc_f16": (_i, [_vp, _vp] + [_i] * 13 + [_vp]),
+    "vip_global_avgpool_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vip_gap_dense_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vip_scale_add_act_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vip_window_attn_fwd_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _vp]),
+}
+
+
+def lib():
+    """Return the loaded library (loading it on first use)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VipError(
+                f"{LIB_PATH} not found: build it with `python vip-cup-2022_amd/build.py` "
+                "(or __graft_entry__.build()); vipcup_amd has no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().vip_last_error().decode("utf-8", "replace")
+        raise VipError(f"{what} failed with vip_status {status}: {msg}")

@@ -1,0 +1,62 @@
+// Shared device/host helpers for libvipcup_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "vipcup_hip.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- host side error plumbing -------------------------------------------------------------
+void vip_set_error(const char* fmt, ...);
+
+#define VIP_REQUIRE(cond, code, ...)          \
+    do {                                      \
+        if (!(cond)) {                        \
+            vip_set_error(__VA_ARGS__);       \
+            return (code);                    \
+        }                                     \
+    } while (0)
+
+static inline int vip_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        vip_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return VIP_ERR_LAUNCH;
+    }
+    return VIP_OK;
+}
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float vip_act(float v, int act) {
+    switch (act) {
+        case VIP_ACT_RELU: return v > 0.f ? v : 0.f;
+        case VIP_ACT_SILU: return v / (1.f + __expf(-v));
+        case VIP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case VIP_ACT_SIGMOID: return 1.f / (1.f + __expf(-v));
+        default: return v;
+    }
+}
+
+union U4H8 {
+    uint4 u;
+    f16x8 h;
+    f16 e[8];
+};
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

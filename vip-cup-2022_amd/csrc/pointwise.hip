@@ -1,0 +1,385 @@
+// HBM-bound NHWC helpers: pooling, global average pool, SE excite + residual + activation,
+// LayerNorm, depthwise convolution.  All of them move 16 bytes (8 halfs) per lane per access and
+// accumulate in fp32.
+#include "common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// pool2d
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool2d_kernel(const f16* __restrict__ x, f16* __restrict__ y, int B, int H,
+                                                     int W, int C8, int ldx, int ldy, int k, int stride, int pt,
+                                                     int pl, int Ho, int Wo, int mode) {
+    const long total = (long)B * Ho * Wo * C8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        long p = idx / C8;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float acc[8];
+        // mode 0: zero padding takes part in the max, so start from the first tap's value (0 if padded)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (mode == 0) ? -3.0e38f : 0.f;
+        int cnt = 0;
+        for (int r = 0; r < k; ++r) {
+            const int hi = ho * stride - pt + r;
+            for (int s = 0; s < k; ++s) {
+                const int wi = wo * stride - pl + s;
+                const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+                U4H8 v;
+                v.u = make_uint4(0, 0, 0, 0);
+                if (ok) {
+                    v.u = *reinterpret_cast<const uint4*>(x + ((long)(b * H + hi) * W + wi) * ldx + c8 * 8);
+                    ++cnt;
+                }
+                if (mode == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], (float)v.e[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += (float)v.e[j];
+                }
+            }
+        }
+        float div = 1.f;
+        if (mode == 1) div = 1.f / (float)(cnt > 0 ? cnt : 1);
+        if (mode == 2) div = 1.f / (float)(k * k);
+        U4H8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = (f16)(acc[j] * div);
+        *reinterpret_cast<uint4*>(y + ((long)(b * Ho + ho) * Wo + wo) * ldy + c8 * 8) = o.u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// global average pool: block = (image, 64-channel slab); 8 chunk lanes x 32 pixel lanes
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gap_kernel(const f16* __restrict__ x, f16* __restrict__ y, int HW, int C,
+                                                  int ldx) {
+    const int b = blockIdx.y;
+    const int c0 = blockIdx.x * 64;
+    const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c = c0 + cl * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (c < C) {
+        const f16* xb = x + (long)b * HW * ldx + c;
+        for (int p = pl; p < HW; p += 32) {
+            U4H8 v;
+            v.u = *reinterpret_cast<const uint4*>(xb + (long)p * ldx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v.e[j];
+        }
+    }
+    __shared__ float red[32][65];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[pl][cl * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int p = 0; p < 32; ++p) s += red[p][threadIdx.x];
+        const int cc = c0 + threadIdx.x;
+        if (cc < C) y[(long)b * C + cc] = (f16)(s / (float)HW);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = act(x * scale[b,c] + residual)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_add_act_kernel(const f16* __restrict__ x, const f16* __restrict__ sc,
+                                                            const f16* __restrict__ res, f16* __restrict__ y,
+                                                            long total8, int HW, int C8, int act) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        const long pix = idx / C8;
+        const int b = (int)(pix / HW);
+        U4H8 v, s, r, o;
+        v.u = *reinterpret_cast<const uint4*>(x + idx * 8);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)v.e[j];
+        if (sc) {
+            s.u = *reinterpret_cast<const uint4*>(sc + ((long)b * C8 + c8) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= (float)s.e[j];
+        }
+        if (res) {
+            r.u = *reinterpret_cast<const uint4*>(res + idx * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += (float)r.e[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = (f16)vip_act(f[j], act);
+        *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over C: LPR lanes per row (power of two, 8..64), CPL 16-byte chunks per lane
+// ---------------------------------------------------------------------------------------------
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, f16* __restrict__ y,
+                                                        int rows, int C, int lpr, float eps) {
+    const int rows_per_block = 256 / lpr;
+    const int sub = threadIdx.x % lpr;
+    const int row = blockIdx.x * rows_per_block + threadIdx.x / lpr;
+    const bool row_ok = row < rows;
+    const int C8 = C >> 3;
+    float v[CPL][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c8 = sub + i * lpr;
+        U4H8 t;
+        t.u = make_uint4(0, 0, 0, 0);
+        if (row_ok && c8 < C8) t.u = *reinterpret_cast<const uint4*>(x + (long)row * C + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[i][j] = (float)t.e[j];
+            sum += v[i][j];
+        }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c8 = sub + i * lpr;
+        if (c8 < C8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[i][j] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c8 = sub + i * lpr;
+        if (row_ok && c8 < C8) {
+            U4H8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c8 * 8 + j;
+                o.e[j] = (f16)((v[i][j] - mean) * rstd * gamma[c] + beta[c]);
+            }
+            *reinterpret_cast<uint4*>(y + (long)row * C + c8 * 8) = o.u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise conv: thread = TW consecutive output columns x 8 channels
+// ---------------------------------------------------------------------------------------------
+template <int K, int S, int TW>
+__global__ __launch_bounds__(256) void dwconv_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+                                                     const float* __restrict__ bias, f16* __restrict__ y, int B,
+                                                     int H, int W, int C8, int pt, int pl, int Ho, int Wo, int act) {
+    constexpr int NCOL = (TW - 1) * S + K;
+    const int WoT = (Wo + TW - 1) / TW;
+    const long total = (long)B * Ho * WoT * C8;
+    const int C = C8 * 8;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        long p = idx / C8;
+        const int wt = (int)(p % WoT);
+        p /= WoT;
+        const int ho = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const int wo0 = wt * TW;
+        float acc[TW][8];
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const int hi = ho * S - pt + r;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            U4H8 col[NCOL];
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) {
+                const int wi = wo0 * S - pl + q;
+                col[q].u = make_uint4(0, 0, 0, 0);
+                if ((unsigned)wi < (unsigned)W)
+                    col[q].u = *reinterpret_cast<const uint4*>(x + ((long)(b * H + hi) * W + wi) * C + c8 * 8);
+            }
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                U4H8 wv;
+                wv.u = *reinterpret_cast<const uint4*>(w + (long)(r * K + s) * C + c8 * 8);
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[t][j] += (float)col[t * S + s].e[j] * (float)wv.e[j];
+            }
+        }
+        float bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[c8 * 8 + j] : 0.f;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const int wo = wo0 + t;
+            if (wo >= Wo) break;
+            U4H8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.e[j] = (f16)vip_act(acc[t][j] + bv[j], act);
+            *reinterpret_cast<uint4*>(y + ((long)(b * Ho + ho) * Wo + wo) * C + c8 * 8) = o.u;
+        }
+    }
+}
+
+inline unsigned grid_for(long total) {
+    long g = (total + 255) / 256;
+    if (g > 256L * 32) g = 256L * 32;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int vip_pool2d_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int k,
+                                   int stride, int pt, int pl, int Ho, int Wo, int mode, void* stream) {
+    VIP_REQUIRE(x && y, VIP_ERR_BAD_ARG, "vip_pool2d_nhwc_f16: null pointer");
+    VIP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && Ho > 0 && Wo > 0 && pt >= 0 && pl >= 0,
+                VIP_ERR_BAD_ARG, "vip_pool2d_nhwc_f16: non-positive dimension");
+    VIP_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, VIP_ERR_ALIGNMENT,
+                "vip_pool2d_nhwc_f16: C/ldx/ldy must be multiples of 8");
+    VIP_REQUIRE(mode >= 0 && mode <= 2, VIP_ERR_BAD_ARG, "vip_pool2d_nhwc_f16: mode %d", mode);
+    const long total = (long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL(pool2d_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
+                       (f16*)y, B, H, W, C / 8, ldx, ldy, k, stride, pt, pl, Ho, Wo, mode);
+    return vip_launch_status("vip_pool2d_nhwc_f16");
+}
+
+extern "C" int vip_global_avgpool_f16(const void* x, void* y, int B, int HW, int C, int ldx, void* stream) {
+    VIP_REQUIRE(x && y, VIP_ERR_BAD_ARG, "vip_global_avgpool_f16: null pointer");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0, VIP_ERR_BAD_ARG, "vip_global_avgpool_f16: non-positive dimension");
+    VIP_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldx >= C, VIP_ERR_ALIGNMENT,
+                "vip_global_avgpool_f16: C/ldx must be multiples of 8");
+    hipLaunchKernelGGL(gap_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y,
+                       HW, C, ldx);
+    return vip_launch_status("vip_global_avgpool_f16");
+}
+
+extern "C" int vip_scale_add_act_f16(const void* x, const void* scale, const void* residual, void* y, int B, int HW,
+                                     int C, int act, void* stream) {
+    VIP_REQUIRE(x && y, VIP_ERR_BAD_ARG, "vip_scale_add_act_f16: null pointer");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && (unsigned)act <= 4u, VIP_ERR_BAD_ARG, "vip_scale_add_act_f16: bad argument");
+    VIP_REQUIRE(C % 8 == 0, VIP_ERR_ALIGNMENT, "vip_scale_add_act_f16: C must be a multiple of 8");
+    const long total8 = (long)B * HW * (C / 8);
+    hipLaunchKernelGGL(scale_add_act_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)x, (const f16*)scale, (const f16*)residual, (f16*)y, total8, HW, C / 8, act);
+    return vip_launch_status("vip_scale_add_act_f16");
+}
+
+extern "C" int vip_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int rows, int C,
+                                 float eps, void* stream) {
+    VIP_REQUIRE(x && y && gamma && beta, VIP_ERR_BAD_ARG, "vip_layernorm_f16: null pointer");
+    VIP_REQUIRE(rows > 0 && C > 0, VIP_ERR_BAD_ARG, "vip_layernorm_f16: non-positive dimension");
+    VIP_REQUIRE(C % 8 == 0, VIP_ERR_ALIGNMENT, "vip_layernorm_f16: C must be a multiple of 8");
+    const int C8 = C / 8;
+    int lpr = 8;
+    while (lpr < 64 && lpr < C8) lpr <<= 1;
+    const int cpl = (C8 + lpr - 1) / lpr;
+    VIP_REQUIRE(cpl <= 4, VIP_ERR_UNSUPPORTED, "vip_layernorm_f16: C=%d too large (max 2048)", C);
+    const int rpb = 256 / lpr;
+    dim3 grid((rows + rpb - 1) / rpb);
+    hipStream_t s = (hipStream_t)stream;
+    const f16* xi = (const f16*)x;
+    f16* yo = (f16*)y;
+    switch (cpl) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, xi, gamma, beta, yo, rows, C, lpr, eps); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, xi, gamma, beta, yo, rows, C, lpr, eps); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, dim3(256), 0, s, xi, gamma, beta, yo, rows, C, lpr, eps); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, xi, gamma, beta, yo, rows, C, lpr, eps); break;
+    }
+    return vip_launch_status("vip_layernorm_f16");
+}
+
+extern "C" int vip_dwconv2d_nhwc_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
+                                     int C, int k, int stride, int pt, int pl, int Ho, int Wo, int act, void* stream) {
+    VIP_REQUIRE(x && w && y, VIP_ERR_BAD_ARG, "vip_dwconv2d_nhwc_f16: null pointer");
+    VIP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && pt >= 0 && pl >= 0 && (unsigned)act <= 4u,
+                VIP_ERR_BAD_ARG, "vip_dwconv2d_nhwc_f16: bad argument");
+    VIP_REQUIRE(C % 8 == 0, VIP_ERR_ALIGNMENT, "vip_dwconv2d_nhwc_f16: C must be a multiple of 8");
+    const int C8 = C / 8;
+    hipStream_t s = (hipStream_t)stream;
+    const f16* xi = (const f16*)x;
+    const f16* wi = (const f16*)w;
+    f16* yo = (f16*)y;
+#define VIP_DW(KK, SS, TW)                                                                                        \
+    {                                                                                                             \
+        const long total = (long)B * Ho * ((Wo + TW - 1) / TW) * C8;                                              \
+        hipLaunchKernelGGL((dwconv_kernel<KK, SS, TW>), dim3(grid_for(total)), dim3(256), 0, s, xi, wi, bias, yo, \
+                           B, H, W, C8, pt, pl, Ho, Wo, act);                                                     \
+    }
+    if (k == 3 && stride == 1) VIP_DW(3, 1, 4)
+    else if (k == 3 && stride == 2) VIP_DW(3, 2, 2)
+    else if (k == 5 && stride == 1) VIP_DW(5, 1, 4)
+    else if (k == 5 && stride == 2) VIP_DW(5, 2, 2)
+    else if (k == 7 && stride == 1) VIP_DW(7, 1, 4)
+    else {
+        vip_set_error("vip_dwconv2d_nhwc_f16: unsupported k=%d stride=%d", k, stride);
+        return VIP_ERR_UNSUPPORTED;
+    }
+#undef VIP_DW
+    return vip_launch_status("vip_dwconv2d_nhwc_f16");
+}
+
+// ---------------------------------------------------------------------------------------------
+// classifier head: global average pool + dense, fp32 out.  One block per image.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void gap_dense_kernel(const f16* __restrict__ x, const float* __restrict__ Wt,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int HW, int C, int ldx, int N) {
+    __shared__ float pooled[4096];
+    __shared__ float wsum[4];
+    const int b = blockIdx.x;
+    const f16* xb = x + (long)b * HW * ldx;
+    const float inv = 1.f / (float)HW;
+    for (int c8 = threadIdx.x; c8 < (C >> 3); c8 += 256) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int p = 0; p < HW; ++p) {
+            U4H8 v;
+            v.u = *reinterpret_cast<const uint4*>(xb + (long)p * ldx + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v.e[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pooled[c8 * 8 + j] = acc[j] * inv;
+    }
+    __syncthreads();
+    for (int n = 0; n < N; ++n) {
+        float s = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) s += pooled[c] * Wt[(long)n * C + c];
+        s = wave_reduce_sum(s);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[(long)b * N + n] = wsum[0] + wsum[1] + wsum[2] + wsum[3] + (bias ? bias[n] : 0.f);
+        __syncthreads();
+    }
+}
+}  // namespace
+
+extern "C" int vip_gap_dense_f32(const void* x, const float* W, const float* bias, float* out, int B, int HW, int C,
+                                 int ldx, int N, void* stream) {
+    VIP_REQUIRE(x && W && out, VIP_ERR_BAD_ARG, "vip_gap_dense_f32: null pointer");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && N > 0, VIP_ERR_BAD_ARG, "vip_gap_dense_f32: non-positive dimension");
+    VIP_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldx >= C, VIP_ERR_ALIGNMENT, "vip_gap_dense_f32: C/ldx must be multiples of 8");
+    VIP_REQUIRE(C <= 4096, VIP_ERR_UNSUPPORTED, "vip_gap_dense_f32: C=%d > 4096", C);
+    hipLaunchKernelGGL(gap_dense_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, W, bias, out, HW,
+                       C, ldx, N);
+    return vip_launch_status("vip_gap_dense_f32");
+}

@@ -1,0 +1,256 @@
+"""Operator layer: torch tensors in, torch tensors out, all arithmetic in libvipcup_hip.so.
+
+PyTorch is used for device memory and streams only.  Activations are fp16, contiguous, NHWC
+(``[B,H,W,C]``) or row-major ``[rows, C]``.  Every function launches on torch's current stream.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _abi
+
+ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "silu": 2, "swish": 2, "gelu": 3, "sigmoid": 4}
+
+
+def _act(a):
+    if isinstance(a, int):
+        return a
+    return ACT[a]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk16(t: torch.Tensor, name: str):
+    if t.dtype != torch.float16 or not t.is_cuda or not t.is_contiguous():
+        raise _abi.VipError(f"{name}: expected a contiguous CUDA float16 tensor, got {t.dtype} {t.device} "
+                            f"contiguous={t.is_contiguous()}")
+
+
+@dataclass
+class ConvWeight:
+    """Device-resident conv / dense weight in the kernel's layout: ``w[Cout][kh*kw*Cin_g (padded to ldw)]``
+    fp16 (filter taps outermost, channels innermost) and an fp32 bias."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    kh: int
+    kw: int
+    cin_g: int
+    cout: int
+    groups: int = 1
+
+    @property
+    def cin(self):
+        return self.cin_g * self.groups
+
+    @property
+    def ldw(self):
+        return self.w.shape[1]
+
+
+def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], groups: int = 1,
+                     device="cuda", pad_cin_to: Optional[int] = None,
+                     pad_cout_to: Optional[int] = None) -> ConvWeight:
+    """Keras HWIO kernel ``[kh,kw,Cin_g,Cout]`` (fp32, BN already folded) -> ConvWeight.
+    (OIHW->HWIO is the reference's own convention, tfimm/utils/timm.py:164-170.)
+    Optionally zero-pads Cin (e.g. RGB 3 -> 8) and Cout (e.g. a 1-class head -> 8)."""
+    kh, kw, cin_g, cout = kernel_hwio.shape
+    k = kernel_hwio.detach().to(torch.float32)
+    if pad_cin_to is not None and pad_cin_to > cin_g:
+        assert groups == 1
+        k = torch.cat([k, k.new_zeros(kh, kw, pad_cin_to - cin_g, cout)], dim=2)
+        cin_g = pad_cin_to
+    b = None if bias is None else bias.detach().to(torch.float32)
+    if pad_cout_to is not None and pad_cout_to > cout:
+        assert groups == 1
+        k = torch.cat([k, k.new_zeros(kh, kw, cin_g, pad_cout_to - cout)], dim=3)
+        if b is not None:
+            b = torch.cat([b, b.new_zeros(pad_cout_to - cout)])
+        cout = pad_cout_to
+    w = k.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin_g)
+    ktot = w.shape[1]
+    ldw = (ktot + 7) // 8 * 8
+    if ldw != ktot:
+        w = torch.cat([w, w.new_zeros(cout, ldw - ktot)], dim=1)
+    return ConvWeight(w=w.to(device=device, dtype=torch.float16).contiguous(),
+                      bias=None if b is None else b.to(device).contiguous(),
+                      kh=kh, kw=kw, cin_g=cin_g, cout=cout, groups=groups)
+
+
+def make_dense_weight(kernel_io: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
+                      pad_cout_to: Optional[int] = None) -> ConvWeight:
+    """Keras Dense kernel ``[in, out]`` -> ConvWeight (1x1)."""
+    return make_conv_weight(kernel_io.reshape(1, 1, *kernel_io.shape), bias, 1, device, None, pad_cout_to)
+
+
+def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None,
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           cin_off: int = 0, cout_off: int = 0) -> torch.Tensor:
+    """y = act_post(act(conv(x) + bias) + residual).  ``pad`` = (top, bottom, left, right) zero padding.
+    ``x`` may carry more channels than the weight consumes (``cin_off`` selects the slice); ``out`` may
+    be a wider tensor written at ``cout_off`` (concat-free channel splits / joins)."""
+    _chk16(x, "conv2d.x")
+    B, H, W, ldx = x.shape
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    pt, pb, pl, pr = pad
+    Ho = (H + pt + pb - cw.kh) // sh + 1
+    Wo = (W + pl + pr - cw.kw) // sw + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, cw.cout), dtype=torch.float16, device=x.device)
+    else:
+        _chk16(out, "conv2d.out")
+        assert out.shape[:3] == (B, Ho, Wo), (out.shape, (B, Ho, Wo))
+    d = _abi.ConvDesc(B=B, H=H, W=W, Cin=cw.cin, Cout=cw.cout, kh=cw.kh, kw=cw.kw, sh=sh, sw=sw, pt=pt, pl=pl,
+                      Ho=Ho, Wo=Wo, groups=cw.groups, ldx=ldx, cin_off=cin_off, ldy=out.shape[3],
+                      cout_off=cout_off, ldr=0, res_off=0, ldw=cw.ldw, act_pre=_act(act), act_post=_act(act_post))
+    if residual is not None:
+        _chk16(residual, "conv2d.residual")
+        assert residual.shape[:3] == (B, Ho, Wo) and residual.shape[3] >= cw.cout
+        d.ldr = residual.shape[3]
+    st = _abi.lib().vip_conv2d_nhwc_f16(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), C.byref(d), _stream())
+    _abi.check(st, "vip_conv2d_nhwc_f16")
+    return out
+
+
+def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Optional[torch.Tensor] = None):
+    """Dense over the last axis of ``x`` (any leading shape)."""
+    _chk16(x, "dense.x")
+    lead = x.shape[:-1]
+    K = x.shape[-1]
+    M = x.numel() // K
+    out = torch.empty((*lead, cw.cout), dtype=torch.float16, device=x.device)
+    ldr = 0
+    if residual is not None:
+        _chk16(residual, "dense.residual")
+        assert residual.shape == out.shape
+        ldr = cw.cout
+    st = _abi.lib().vip_gemm_bias_act_f16(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), M, cw.cout, K,
+                                          K, cw.ldw, cw.cout, ldr, _act(act), _act(act_post), _stream())
+    _abi.check(st, "vip_gemm_bias_act_f16")
+    return out
+
+
+def dwconv2d(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride=1, pad=(0, 0, 0, 0), act=None):
+    """Depthwise conv; ``w_khwc`` fp16 ``[k,k,C]``, bias fp32 ``[C]``."""
+    _chk16(x, "dwconv2d.x")
+    B, H, W, Cc = x.shape
+    pt, pb, pl, pr = pad
+    Ho = (H + pt + pb - k) // stride + 1
+    Wo = (W + pl + pr - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float16, device=x.device)
+    st = _abi.lib().vip_dwconv2d_nhwc_f16(_p(x), _p(w_khwc), _p(bias), _p(out), B, H, W, Cc, k, stride, pt, pl,
+                                          Ho, Wo, _act(act), _stream())
+    _abi.check(st, "vip_dwconv2d_nhwc_f16")
+    return out
+
+
+def layernorm(x, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    _chk16(x, "layernorm.x")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    out = torch.empty_like(x)
+    st = _abi.lib().vip_layernorm_f16(_p(x), _p(gamma), _p(beta), _p(out), rows, Cc, float(eps), _stream())
+    _abi.check(st, "vip_layernorm_f16")
+    return out
+
+
+POOL_MAX_ZEROPAD, POOL_AVG_VALID, POOL_AVG_FULL = 0, 1, 2
+
+
+def pool2d(x, k: int, stride: int, pad=(0, 0, 0, 0), mode=POOL_MAX_ZEROPAD):
+    _chk16(x, "pool2d.x")
+    B, H, W, Cc = x.shape
+    pt, pb, pl, pr = pad
+    Ho = (H + pt + pb - k) // stride + 1
+    Wo = (W + pl + pr - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float16, device=x.device)
+    st = _abi.lib().vip_pool2d_nhwc_f16(_p(x), _p(out), B, H, W, Cc, Cc, Cc, k, stride, pt, pl, Ho, Wo, mode,
+                                        _stream())
+    _abi.check(st, "vip_pool2d_nhwc_f16")
+    return out
+
+
+def global_avgpool(x):
+    """[B,H,W,C] (or [B,N,C]) -> [B,C]"""
+    _chk16(x, "global_avgpool.x")
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    out = torch.empty((B, Cc), dtype=torch.float16, device=x.device)
+    st = _abi.lib().vip_global_avgpool_f16(_p(x), _p(out), B, HW, Cc, Cc, _stream())
+    _abi.check(st, "vip_global_avgpool_f16")
+    return out
+
+
+def gap_dense_f32(x, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Classifier head: mean over the middle axes of ``x`` ([B,...,C]) then Dense -> fp32 ``[B,N]``.
+    ``w_nc`` fp32 ``[N,C]``."""
+    _chk16(x, "gap_dense_f32.x")
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    N = w_nc.shape[0]
+    assert w_nc.dtype == torch.float32 and w_nc.shape == (N, Cc) and w_nc.is_contiguous()
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    st = _abi.lib().vip_gap_dense_f32(_p(x), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, N, _stream())
+    _abi.check(st, "vip_gap_dense_f32")
+    return out
+
+
+def scale_add_act(x, scale=None, residual=None, act=None):
+    """act(x * scale[b,c] + residual)"""
+    _chk16(x, "scale_add_act.x")
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    if scale is not None:
+        _chk16(scale, "scale_add_act.scale")
+        assert scale.shape == (B, Cc)
+    if residual is not None:
+        _chk16(residual, "scale_add_act.residual")
+        assert residual.shape == x.shape
+    out = torch.empty_like(x)
+    st = _abi.lib().vip_scale_add_act_f16(_p(x), _p(scale), _p(residual), _p(out), B, HW, Cc, _act(act), _stream())
+    _abi.check(st, "vip_scale_add_act_f16")
+    return out
+
+
+def window_attention(qkv, q_global, bias_table, heads: int, ws: int, scale: float):
+    """GCViT window attention core on feature-map layout.  qkv ``[B,Hp,Wp,nq*C]``; q_global ``[B,ws*ws,C]`` or None."""
+    _chk16(qkv, "window_attention.qkv")
+    B, Hp, Wp, CC = qkv.shape
+    nq = 2 if q_global is not None else 3
+    Cc = CC // nq
+    if q_global is not None:
+        _chk16(q_global, "window_attention.q_global")
+        assert q_global.numel() == B * ws * ws * Cc
+    assert bias_table.dtype == torch.float32 and bias_table.shape == ((2 * ws - 1) ** 2, heads)
+    out = torch.empty((B, Hp, Wp, Cc), dtype=torch.float16, device=qkv.device)
+    st = _abi.lib().vip_window_attn_fwd_f16(_p(qkv), _p(q_global), _p(bias_table), _p(out), B, Hp, Wp, Cc, heads,
+                                            ws, nq, float(scale), _stream())
+    _abi.check(st, "vip_window_attn_fwd_f16")
+    return out
+
+
+def mhsa(qkv, heads: int, scale: float):
+    """ViT attention core: qkv ``[B,N,3D]`` -> ``[B,N,D]``."""
+    _chk16(qkv, "mhsa.qkv")
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    out = torch.empty((B, N, D), dtype=torch.float16, device=qkv.device)
+    st = _abi.lib().vip_mhsa_fwd_f16(_p(qkv), _p(out), B, N, D, heads, float(scale), _stream())
+    _abi.check(st, "vip_mhsa_fwd_f16")
+    return out
+
+
+def to_device_nhwc8(x_nhwc3: torch.Tensor, device="cuda") -> torch.Tensor:
+    """Plumbing for callers that already hold decoded float images: [B,H,W,3] float -> fp16 NHWC with the
+    channel axis zero-padded to 8 (the layout vip_resize_bicubic_norm_f16 emits)."""
+    B, H, W, Cc = x_nhwc3.shape
+    out = torch.zeros((B, H, W, 8), dtype=torch.float16, device=device)
+    out[..., :Cc] = x_nhwc3.to(device=device, dtype=torch.float16)
+    return out
