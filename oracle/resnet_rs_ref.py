@@ -65,13 +65,19 @@ def bottleneck(p, name, x, strides, use_projection, eps, act, se_ratio):
     return R.act(y + shortcut, act)
 
 
-def forward_features(p, x, depth=50, eps=1e-5, act="relu", se_ratio=0.25, first_strides=2, block_args=None):
-    """ResNetRS (:329-513) up to the last block; x float32 NHWC [B,H,W,3] in [0,1]."""
+def forward_features(p, x, depth=50, eps=1e-5, act="relu", se_ratio=0.25, first_strides=2, block_args=None,
+                     collect=None):
+    """ResNetRS (:329-513) up to the last block; x float32 NHWC [B,H,W,3] in [0,1].
+    ``collect``: optional list receiving the stem output and every block output (diagnostics)."""
     x = stem(p, x, eps, act, first_strides)
+    if collect is not None:
+        collect.append(x)
     for gi, (f, reps) in enumerate(block_args or BLOCK_ARGS[depth]):
         for bi in range(reps):
             x = bottleneck(p, f"c{gi + 2}_block_{bi}_", x, (1 if gi == 0 else 2) if bi == 0 else 1, bi == 0, eps,
                            act, se_ratio)
+            if collect is not None:
+                collect.append(x)
     return x
 
 
@@ -79,3 +85,9 @@ def forward_logits(p, x, **kw):
     """head (:468-476): GAP -> (Dropout no-op) -> Dense; returns pre-activation logits [B, classes]."""
     f = forward_features(p, x, **kw)
     return R.dense(R.global_avgpool(f), p["predictions/kernel"], p["predictions/bias"])
+
+
+def predict_logits(member, params, x):
+    """Uniform entry used by tests / bench: member name -> logits."""
+    assert member == "resnet_rs50"
+    return forward_logits(params, x, depth=50)

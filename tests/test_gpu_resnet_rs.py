@@ -51,6 +51,6 @@ def test_resnet_rs_tiny(report):
 def test_resnet_rs50_full(report):
     """Full ResNet-RS-50 at 200x200 on 8 synthetic images: logits vs the fp32 oracle."""
     fe, frms, ze, z_ref = _run(None, 200, 8, report, "rs50", 1006)
-    assert frms < 1e-2
+    assert frms < 3e-3
     # raw (uncalibrated) synthetic head: compare relative to the logit scale
     assert ze < 2e-3 * max(1.0, z_ref.abs().max().item())

@@ -3,6 +3,11 @@ is absent (there is deliberately no CPU fallback)."""
 import ctypes as C
 import os
 
+# torch must load ITS libamdhip64 first: libvipcup_hip.so then binds to that same runtime instance (same
+# SONAME), so device pointers and streams are shared.  Loaded the other way round the process ends up with
+# two HIP runtimes and every launch fails with "no ROCm-capable device".
+import torch  # noqa: F401  (side effect: HIP runtime)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvipcup_hip.so")
 

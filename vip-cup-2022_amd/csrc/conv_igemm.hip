@@ -10,12 +10,13 @@
 // Orientation: the WEIGHT fragment is the MFMA "A" operand and the ACTIVATION fragment the "B"
 // operand, so each lane ends up holding 4 consecutive output channels of one pixel per MFMA; the
 // weight rows a wave feeds to its 4 n-tiles are interleaved (row r of n-tile t = channel
-// (r>>2)*16 + t*4 + (r&3)) so that one lane owns 16 CONSECUTIVE channels of a pixel and the
-// epilogue (bias, activation, residual) runs on 16-byte vectors and stores whole 128-byte lines.
+// (t>>1)*32 + (r>>2)*8 + (t&1)*4 + (r&3)) so that one lane owns two runs of 8 consecutive channels of a
+// pixel, the epilogue (bias, activation, residual) runs on 16-byte vectors, and the four lanes of a
+// pixel write 64 contiguous bytes per store instruction.
 //
 // LDS image: 128-byte rows (64 halfs), 16-byte chunks XOR-swizzled so that every ds_read_b128 of
 // a fragment is bank-conflict free: activation rows use key row&7, weight rows (read in the
-// interleaved order above) use key ((row>>4)&3)<<1 | ((row>>1)&1).
+// interleaved order above) use key ((row>>3)&3)<<1 | ((row>>1)&1).
 //
 // Replaces Conv2D+BN+Activation(+Add) of the reference (resnet_rs_model.py:64-84,235-280;
 // kecam common_layers.py:190-248; tfimm convnext.py:260-267,320-327) and every Dense layer.
@@ -35,14 +36,78 @@ struct ConvArgs {
     int ldx, ldy, ldr, ldw;
     int cin_off, cout_off, res_off;
     int M, K;
+    long x_span_bytes;  // bytes from x (the tensor base) to the end of the input tensor
+    long y_span_bytes, res_span_bytes;
+    int bias_elems;
     int act_pre, act_post;
     int m_blocks, n_blocks;
 };
 
 __device__ __forceinline__ int swz_x(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 __device__ __forceinline__ int swz_w(int row, int chunk) {
-    const int key = (((row >> 4) & 3) << 1) | ((row >> 1) & 1);
+    const int key = (((row >> 3) & 3) << 1) | ((row >> 1) & 1);
     return row * 128 + ((chunk ^ key) << 4);
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_t(float v) {
+    if constexpr (ACT == VIP_ACT_RELU) return v > 0.f ? v : 0.f;
+    else if constexpr (ACT == VIP_ACT_SILU) return v / (1.f + __expf(-v));
+    else if constexpr (ACT == VIP_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    else if constexpr (ACT == VIP_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    else return v;
+}
+
+// Lane owns channels n_first + h*32 + (0..7), h = 0,1, of pixel rows m_base + mt*16.  Branch-free: bias /
+// residual / output go through buffer descriptors; masked lanes use an out-of-range offset (loads return
+// 0, stores are dropped).
+template <int MT, int ACT>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, f32x4 (&acc)[MT][4], int m_base, int n_first, int group) {
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int ch_glob = group * a.Cout_g;
+    const __amdgpu_buffer_rsrc_t rb_bias =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)(a.bias_elems * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_res =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (unsigned)a.res_span_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (unsigned)a.y_span_bytes, 0x00020000);
+    f32x4 bv[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = n_first + h * 32;
+        const unsigned off = (n < a.Cout_g) ? (unsigned)((ch_glob + n) * 4) : OOB;
+        bv[h][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_bias, off, 0, 0));
+        bv[h][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_bias, off, 16, 0));
+    }
+    const bool post_relu = a.act_post == VIP_ACT_RELU;
+    const bool post_other = a.act_post != VIP_ACT_NONE && !post_relu;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m_base + mt * 16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = n_first + h * 32;
+            const bool ok = (m < a.M) & (n < a.Cout_g);
+            U4H8 r;
+            r.u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                rb_res, ok ? (unsigned)((m * a.ldr + a.res_off + ch_glob + n) * 2) : OOB, 0, 0));
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[j] = act_t<ACT>(acc[mt][h * 2 + (j >> 2)][j & 3] + bv[h][j >> 2][j & 3]) + (float)r.e[j];
+                if (post_relu) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (post_other) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = vip_act(v[j], a.act_post);
+            }
+            U4H8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.e[j] = (f16)v[j];
+            __builtin_amdgcn_raw_buffer_store_b128(
+                __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o.u), rb_y,
+                ok ? (unsigned)((m * a.ldy + a.cout_off + ch_glob + n) * 2) : OOB, 0, 0);
+        }
+    }
 }
 
 template <int BM, int BN>
@@ -84,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int chunk = tid & 7;
     const int row0 = tid >> 3;  // + 32*i
     int hi0[A_IT], wi0[A_IT];
-    long pix0[A_IT];
+    int pix0[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int m = m0 + row0 + 32 * i;
@@ -96,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const int wo = rem - ho * a.Wo;
             hi0[i] = ho * a.sh - a.pt;
             wi0[i] = wo * a.sw - a.pl;
-            pix0[i] = (long)b * a.H * a.W;
+            pix0[i] = b * a.H * a.W;
         } else {
             hi0[i] = -(1 << 28);
             wi0[i] = 0;
@@ -111,22 +176,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 
     uint4 ra[A_IT], rb[B_IT];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    // Buffer descriptors: out-of-range offsets read as zero in hardware, so padding taps, the M/N/K
+    // tails and masked rows cost no branch (a "cond ? load : 0" in HIP source compiles to a branch around
+    // every load plus a vmcnt(0) per load — 8 dependent memory round trips per k-tile).
+    const unsigned x_bytes = (unsigned)min((long)0xFFFFFFF0L, a.x_span_bytes - 2L * (a.cin_off + group * a.Cin_g));
+    const unsigned w_bytes = (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xg, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
 
     auto load_tiles = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             const int hi = hi0[i] + tr, wi = wi0[i] + ts;
-            const bool ok = (tr < a.kh) && ((unsigned)hi < (unsigned)a.H) && ((unsigned)wi < (unsigned)a.W);
-            const long off = (pix0[i] + (long)hi * a.W + wi) * a.ldx + cc;
-            ra[i] = ok ? *reinterpret_cast<const uint4*>(xg + off) : zero4;
+            const bool ok = (tr < a.kh) & ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);
+            const unsigned off = (unsigned)(((pix0[i] + hi * a.W + wi) * a.ldx + cc) * 2);
+            ra[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : OOB, 0, 0));
         }
         const int k = kt * 64 + chunk * 8;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             const int n = n0 + row0 + 32 * i;
-            const bool ok = (n < a.Cout_g) && (k < a.K);
-            rb[i] = ok ? *reinterpret_cast<const uint4*>(wg + (size_t)n * a.ldw + k) : zero4;
+            const bool ok = (n < a.Cout_g) & (k < a.K);
+            const unsigned off = (unsigned)((n * a.ldw + k) * 2);
+            rb[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? off : OOB, 0, 0));
         }
         // advance the filter position by one k-tile (64 halfs)
         cc += 64;
@@ -148,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int wave_m0 = (wave / WAVES_N) * WTM;
     const int wave_n0 = (wave % WAVES_N) * 64;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int wrow_base = wave_n0 + (l15 >> 2) * 16 + (l15 & 3);  // + nt*4
+    const int wrow_base = wave_n0 + (l15 >> 2) * 8 + (l15 & 3);  // + (nt>>1)*32 + (nt&1)*4
     const int xrow_base = wave_m0 + l15;                          // + mt*16
 
     f32x4 acc[MT][4];
@@ -172,7 +246,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const int ch = ks * 4 + lq;
             U4H8 wf[4], xf[MT];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(sb + swz_w(wrow_base + nt * 4, ch));
+            for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(sb + swz_w(wrow_base + (nt >> 1) * 32 + (nt & 1) * 4, ch));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[mt].u = *reinterpret_cast<const uint4*>(sa + swz_x(xrow_base + mt * 16, ch));
 #pragma unroll
@@ -185,39 +259,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns channels n_first .. n_first+15 of pixel rows m (one per m-tile) ----
-    const int n_first = n0 + wave_n0 + lq * 16;
-    const int ch_glob = group * a.Cout_g;
-    float bv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) bv[j] = 0.f;
-    if (a.bias) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (n_first + j < a.Cout_g) bv[j] = a.bias[ch_glob + n_first + j];
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wave_m0 + mt * 16 + l15;
-        if (m >= a.M) continue;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int n = n_first + h * 8;
-            if (n >= a.Cout_g) continue;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = vip_act(acc[mt][h * 2 + (j >> 2)][j & 3] + bv[h * 8 + j], a.act_pre);
-            if (a.res) {
-                U4H8 r;
-                r.u = *reinterpret_cast<const uint4*>(a.res + (size_t)m * a.ldr + a.res_off + ch_glob + n);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)r.e[j];
-            }
-            U4H8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o.e[j] = (f16)vip_act(v[j], a.act_post);
-            *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldy + a.cout_off + ch_glob + n) = o.u;
-        }
+    // ---- epilogue (one instantiation per activation so the per-element code is straight-line) ----
+    const int m_base = m0 + wave_m0 + l15;
+    const int n_first = n0 + wave_n0 + lq * 8;
+    switch (a.act_pre) {
+        case VIP_ACT_RELU: epilogue<MT, VIP_ACT_RELU>(a, acc, m_base, n_first, group); break;
+        case VIP_ACT_SILU: epilogue<MT, VIP_ACT_SILU>(a, acc, m_base, n_first, group); break;
+        case VIP_ACT_GELU: epilogue<MT, VIP_ACT_GELU>(a, acc, m_base, n_first, group); break;
+        case VIP_ACT_SIGMOID: epilogue<MT, VIP_ACT_SIGMOID>(a, acc, m_base, n_first, group); break;
+        default: epilogue<MT, VIP_ACT_NONE>(a, acc, m_base, n_first, group); break;
     }
 }
 
@@ -226,11 +276,12 @@ int launch(const ConvArgs& a0, int groups, hipStream_t s) {
     ConvArgs a = a0;
     a.m_blocks = (a.M + BM - 1) / BM;
     a.n_blocks = (a.Cout_g + BN - 1) / BN;
-    const size_t smem = 2 * (BM + BN) * 128;
+    const int nk = (a.K + 63) >> 6;
+    const size_t smem = (nk == 1 ? 1 : 2) * (BM + BN) * 128;  // a single k-tile needs no second stage
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * 128);
         attr_set = true;
     }
     dim3 grid((unsigned)(a.m_blocks * a.n_blocks), 1, (unsigned)groups);
@@ -271,6 +322,14 @@ extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bi
     a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.ldw = d->ldw;
     a.cin_off = d->cin_off; a.cout_off = d->cout_off; a.res_off = d->res_off;
     a.M = (int)M; a.K = d->kh * d->kw * cin_g;
+    a.x_span_bytes = 2L * d->B * d->H * d->W * d->ldx;
+    a.y_span_bytes = 2L * M * d->ldy;
+    a.res_span_bytes = 2L * M * d->ldr;
+    a.bias_elems = d->Cout;
+    VIP_REQUIRE(a.y_span_bytes < 0xFFFFFFF0L && a.res_span_bytes < 0xFFFFFFF0L, VIP_ERR_UNSUPPORTED,
+                "vip_conv2d_nhwc_f16: output or residual tensor exceeds the 4 GiB buffer-addressing range");
+    VIP_REQUIRE(a.x_span_bytes < 0xFFFFFFF0L && 2L * d->Cout * d->ldw < 0xFFFFFFF0L, VIP_ERR_UNSUPPORTED,
+                "vip_conv2d_nhwc_f16: input or weight tensor exceeds the 4 GiB buffer-addressing range");
     a.act_pre = d->act_pre; a.act_post = d->act_post;
     a.m_blocks = a.n_blocks = 0;
     hipStream_t s = (hipStream_t)stream;

@@ -14,6 +14,15 @@ from . import _abi
 ACT = {None: 0, "none": 0, "linear": 0, "relu": 1, "silu": 2, "swish": 2, "gelu": 3, "sigmoid": 4}
 
 
+_PROF = None
+
+
+def set_profiler(p):
+    """Install (or clear with None) a per-launch profiler: an object with start(family, flops, bytes) / stop(tok)."""
+    global _PROF
+    _PROF = p
+
+
 def _act(a):
     if isinstance(a, int):
         return a
@@ -45,6 +54,7 @@ class ConvWeight:
     cin_g: int
     cout: int
     groups: int = 1
+    alg_cin_g: int = 0   # un-padded input channels per group (algorithmic FLOP count)
 
     @property
     def cin(self):
@@ -62,6 +72,7 @@ def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], gr
     (OIHW->HWIO is the reference's own convention, tfimm/utils/timm.py:164-170.)
     Optionally zero-pads Cin (e.g. RGB 3 -> 8) and Cout (e.g. a 1-class head -> 8)."""
     kh, kw, cin_g, cout = kernel_hwio.shape
+    alg_cin_g = cin_g
     k = kernel_hwio.detach().to(torch.float32)
     if pad_cin_to is not None and pad_cin_to > cin_g:
         assert groups == 1
@@ -81,7 +92,7 @@ def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], gr
         w = torch.cat([w, w.new_zeros(cout, ldw - ktot)], dim=1)
     return ConvWeight(w=w.to(device=device, dtype=torch.float16).contiguous(),
                       bias=None if b is None else b.to(device).contiguous(),
-                      kh=kh, kw=kw, cin_g=cin_g, cout=cout, groups=groups)
+                      kh=kh, kw=kw, cin_g=cin_g, cout=cout, groups=groups, alg_cin_g=alg_cin_g)
 
 
 def make_dense_weight(kernel_io: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
@@ -114,7 +125,15 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
         _chk16(residual, "conv2d.residual")
         assert residual.shape[:3] == (B, Ho, Wo) and residual.shape[3] >= cw.cout
         d.ldr = residual.shape[3]
+    tok = None
+    if _PROF is not None:
+        M = B * Ho * Wo
+        kk = cw.kh * cw.kw * cw.alg_cin_g
+        tok = _PROF.start("conv_igemm_kernel", 2.0 * M * cw.cout * kk,
+                          2.0 * (B * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()))
     st = _abi.lib().vip_conv2d_nhwc_f16(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), C.byref(d), _stream())
+    if tok is not None:
+        _PROF.stop(tok)
     _abi.check(st, "vip_conv2d_nhwc_f16")
     return out
 
@@ -131,8 +150,14 @@ def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Op
         _chk16(residual, "dense.residual")
         assert residual.shape == out.shape
         ldr = cw.cout
+    tok = None
+    if _PROF is not None:
+        tok = _PROF.start("conv_igemm_kernel", 2.0 * M * cw.cout * K,
+                          2.0 * (M * K + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()))
     st = _abi.lib().vip_gemm_bias_act_f16(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), M, cw.cout, K,
                                           K, cw.ldw, cw.cout, ldr, _act(act), _act(act_post), _stream())
+    if tok is not None:
+        _PROF.stop(tok)
     _abi.check(st, "vip_gemm_bias_act_f16")
     return out
 
@@ -230,8 +255,17 @@ def window_attention(qkv, q_global, bias_table, heads: int, ws: int, scale: floa
         assert q_global.numel() == B * ws * ws * Cc
     assert bias_table.dtype == torch.float32 and bias_table.shape == ((2 * ws - 1) ** 2, heads)
     out = torch.empty((B, Hp, Wp, Cc), dtype=torch.float16, device=qkv.device)
+    tok = None
+    if _PROF is not None:
+        # algorithmic work of the attention core: 4*N^2*hd FLOPs and 4*N*hd fp16 elements
+        # (q, k, v read + out written) per (window, head)
+        nwh = B * (Hp // ws) * (Wp // ws) * heads
+        N = ws * ws
+        tok = _PROF.start("window_attn_kernel", nwh * 4.0 * N * N * 32, nwh * 4.0 * N * 32 * 2)
     st = _abi.lib().vip_window_attn_fwd_f16(_p(qkv), _p(q_global), _p(bias_table), _p(out), B, Hp, Wp, Cc, heads,
                                             ws, nq, float(scale), _stream())
+    if tok is not None:
+        _PROF.stop(tok)
     _abi.check(st, "vip_window_attn_fwd_f16")
     return out
 

@@ -51,7 +51,9 @@ def synth_params(depth: int = 50, seed: int = 1006, classes: int = 1, se_ratio: 
             g.bn(n + "batch_norm_1", f)
             g.conv(n + "conv_2", 3, 3, f, f)
             g.bn(n + "batch_norm_2", f)
-            g.conv(n + "conv_3", 1, 1, f, 4 * f)
+            # damped residual branch (the reference zero-initialises the block-final BN gamma; an undamped
+            # random 16-block ReLU net is chaotic: it doubles any perturbation per block)
+            g.conv(n + "conv_3", 1, 1, f, 4 * f, gain=0.25)
             g.bn(n + "batch_norm_3", 4 * f)
             if 0 < se_ratio < 1:
                 r = max(1, int(f * 4 * se_ratio))
@@ -122,7 +124,7 @@ class ResNetRS:
             scale = ops.dense(sq, blk["se_e"], act="sigmoid")
         return ops.scale_add_act(y, scale, shortcut, self.act)
 
-    def features(self, x: torch.Tensor) -> torch.Tensor:
+    def features(self, x: torch.Tensor, collect=None) -> torch.Tensor:
         """x: fp16 NHWC with the RGB axis zero-padded to 8 channels."""
         assert x.shape[-1] == 8, "input must be NHWC fp16 with channels padded to 8"
         fs = self.first_strides
@@ -131,8 +133,12 @@ class ResNetRS:
         y = ops.conv2d(y, self.stem[1], pad=(1, 1, 1, 1), act=self.act)
         y = ops.conv2d(y, self.stem[2], pad=(1, 1, 1, 1), act=self.act)
         y = ops.conv2d(y, self.stem[3], stride=2, pad=fixed_padding(3), act=self.act)
+        if collect is not None:
+            collect.append(y)
         for blk in self.blocks:
             y = self._bottleneck(y, blk)
+            if collect is not None:
+                collect.append(y)
         return y
 
     def logits(self, x: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,123 @@
+"""Benchmark workloads: which ensemble members run, on what resident input, and how a step is timed.
+
+Used by bench.py and __graft_entry__.smoke().  No oracle imports here (the CPU baseline lives in
+bench.py).
+"""
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from . import zoo
+
+DEFAULT = "resnet_rs50"
+
+
+class KernelProfile:
+    """HIP-event bracketing of individual launches on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        self.rec: List = []
+
+    def start(self, family: str, flops: float, nbytes: float):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return (family, flops, nbytes, e0, e1)
+
+    def stop(self, tok):
+        tok[4].record()
+        self.rec.append(tok)
+
+    def summary(self) -> Dict[str, Dict[str, float]]:
+        torch.cuda.synchronize()
+        out: Dict[str, Dict[str, float]] = {}
+        for fam, fl, nb, e0, e1 in self.rec:
+            d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+class Workload:
+    def __init__(self, name: str, members: List[str], batch: int, rank: int, world: int):
+        self.name = name
+        self.batch = batch
+        self.rank = rank
+        self.world = world
+        self.members = members
+        self.models = [zoo.build_member(m) for m in members]
+        g = torch.Generator().manual_seed(1234 + rank)
+        self.inputs = {}
+        for spec, _ in self.models:
+            hw = spec.input_hw
+            if hw not in self.inputs:
+                x = torch.zeros((batch, hw, hw, 8), dtype=torch.float16, device="cuda")
+                x[..., :3] = torch.rand((batch, hw, hw, 3), generator=g).to(device="cuda", dtype=torch.float16)
+                self.inputs[hw] = x
+        self.scores = None
+        self._gather = None
+
+    def step(self, dist=None):
+        """Score the resident batch with every member; mean over members (main.py:142-143); all-gather."""
+        probs = []
+        for spec, model in self.models:
+            probs.append(model.predict(self.inputs[spec.input_hw]))
+        s = torch.stack(probs, 0).mean(0).reshape(-1)
+        if dist is not None and self.world > 1:
+            if self._gather is None:
+                self._gather = torch.empty((self.world, s.numel()), dtype=s.dtype, device=s.device)
+            dist.all_gather_into_tensor(self._gather, s)
+            s = self._gather
+        self.scores = s
+        return s
+
+    def config(self):
+        return {"workload": self.name, "members": self.members, "batch_per_gpu": self.batch,
+                "global_batch": self.batch * self.world, "input": "200x200 RGB -> member resolution, fp16 NHWC resident",
+                "parallelism": f"image-parallel dp{self.world}, all-gather of scores"}
+
+    def roofline(self, peak_tflops: float, peak_gbs: float):
+        """One instrumented step: per-kernel-family time from HIP events around each launch."""
+        prof = KernelProfile()
+        ops.set_profiler(prof)
+        try:
+            self.step(None)
+        finally:
+            ops.set_profiler(None)
+        summ = prof.summary()
+        self._summ = summ
+        if not summ:
+            return None
+        fam = max(summ, key=lambda k: summ[k]["ms"])
+        d = summ[fam]
+        sec = d["ms"] * 1e-3
+        tf = d["flops"] / sec / 1e12
+        gbs = d["bytes"] / sec / 1e9
+        intensity = d["flops"] / max(d["bytes"], 1.0)
+        if intensity * peak_gbs * 1e9 >= peak_tflops * 1e12:
+            return {"kernel": fam, "bound": "mfma", "achieved": tf, "peak": peak_tflops, "unit": "TFLOP/s",
+                    "frac": tf / peak_tflops, "traffic": None, "launches": d["launches"],
+                    "avg_launch_ms": d["ms"] / d["launches"]}
+        return {"kernel": fam, "bound": "hbm", "achieved": gbs, "peak": peak_gbs, "unit": "GB/s",
+                "frac": gbs / peak_gbs, "traffic": None, "launches": d["launches"],
+                "avg_launch_ms": d["ms"] / d["launches"]}
+
+    def extra(self):
+        summ = getattr(self, "_summ", None)
+        if not summ:
+            return None
+        return {k: {"launches": v["launches"], "ms_per_step": round(v["ms"], 4),
+                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
+                    "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
+                for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def build(name: str, batch: int, rank: int = 0, world: int = 1) -> Workload:
+    if name == "ensemble":
+        members = zoo.ENSEMBLE
+    else:
+        members = [name]
+    return Workload(name, members, batch, rank, world)

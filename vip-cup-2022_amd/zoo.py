@@ -1,0 +1,38 @@
+"""Ensemble member registry — the MI355X counterpart of the reference's ckpts/ckpts.json manifest
+(``[name, [H, W], idx]``, main.py:171-198) plus the model constructors main.py:28-37 imports.
+
+No trained checkpoints ship with the reference (README.md:13), so each member is instantiated from its
+seeded synthetic checkpoint (synth.py); ``params`` dictionaries use the reference's Keras variable names.
+"""
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Tuple
+
+from . import resnet_rs
+
+
+@dataclass
+class MemberSpec:
+    name: str            # registry key
+    ckpt_name: str       # directory name in the reference manifest (ckpts/ckpts.json)
+    input_hw: int        # square input resolution from the manifest
+    seed: int            # synthetic-checkpoint seed (1000 + manifest index)
+    synth: Callable      # seed -> params dict
+    ctor: Callable       # params -> model with .logits(x) / .predict(x)
+    oracle: str          # module under oracle/ that restates the graph (used by tests / bench cpu leg only)
+    gmac_per_image: float  # algorithmic GMAC / image
+
+
+MEMBERS: Dict[str, MemberSpec] = {
+    "resnet_rs50": MemberSpec("resnet_rs50", "ResNetRS50-200x200", 200, 1006,
+                              lambda seed: resnet_rs.synth_params(50, seed),
+                              lambda p: resnet_rs.ResNetRS50(p), "resnet_rs_ref", 3.790),
+}
+
+# order of ckpts/ckpts.json:2-8 (members are appended here as their graphs land)
+ENSEMBLE: List[str] = ["resnet_rs50"]
+
+
+def build_member(name: str, seed: int = None) -> Tuple[MemberSpec, object]:
+    spec = MEMBERS[name]
+    params = spec.synth(spec.seed if seed is None else seed)
+    return spec, spec.ctor(params)
