@@ -124,15 +124,19 @@ def level(p, name, x, depth, heads, ws, keep_dims, downsample):
     return x
 
 
-def forward_features(p, x, cfg):
+def forward_features(p, x, cfg, collect=None):
     """GCViT.forward_features (models/gcvit.py:98-105): Stem -> levels -> LN"""
     # Stem (layers/embedding.py:19-23): ZeroPad(1) -> Conv3x3/2 (bias) -> ReduceSize(keep_dim)
     x = R.conv2d(x, p["patch_embed/proj/kernel"], p["patch_embed/proj/bias"], 2, (1, 1, 1, 1))
     x = reduce_size(p, "patch_embed/conv_down", x)
+    if collect is not None:
+        collect.append(x)
     n = len(cfg["depths"])
     for i in range(n):
         x = level(p, f"levels/{i}", x, cfg["depths"][i], cfg["num_heads"][i], cfg["window_size"][i], KEEP_DIMS[i],
                   i < n - 1)
+        if collect is not None:
+            collect.append(x)
     return _ln(p, "norm", x)
 
 
@@ -140,3 +144,8 @@ def forward_logits(p, x, cfg):
     """forward_head (models/gcvit.py:107-113): GAP -> Dense (pre-activation)"""
     f = forward_features(p, x, cfg)
     return R.dense(R.global_avgpool(f), p["head/kernel"], p["head/bias"])
+
+
+def predict_logits(member, params, x):
+    """Uniform entry used by tests / bench: member name -> logits."""
+    return forward_logits(params, x, NAME2CONFIG[member])

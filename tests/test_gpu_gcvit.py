@@ -1,0 +1,47 @@
+"""GPU parity of the GCViT path (BASELINE config 3) against the fp32 CPU oracle."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gcvit_ref as ref  # noqa: E402
+from tests.test_gpu_resnet_rs import _images  # noqa: E402
+
+
+def _run(cfg, n, report, tag, seed=1002):
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import gcvit, ops
+    x = _images(n, 224).to(torch.float16).to(torch.float32)
+    p = gcvit.synth_params(cfg, seed=seed)
+    ca, cb = [], []
+    with torch.no_grad():
+        f_ref = ref.forward_features(p, x, cfg, collect=ca)
+        z_ref = ref.forward_logits(p, x, cfg)
+    m = gcvit.GCViT(p, **cfg)
+    xd = ops.to_device_nhwc8(x)
+    f = m.features(xd, collect=cb).float().cpu()
+    z = m.logits(xd).cpu()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(ca, cb)):
+        b = b.float().cpu()
+        report(f"[gcvit {tag}] stage {i} shape {tuple(a.shape)} ref_rms {a.pow(2).mean().sqrt().item():.3f} "
+               f"rel_rms_err {((a - b) ** 2).mean().sqrt().item() / a.pow(2).mean().sqrt().item():.3e}")
+    frms = ((f - f_ref) ** 2).mean().sqrt().item() / f_ref.pow(2).mean().sqrt().item()
+    ze = (z - z_ref).abs().max().item()
+    report(f"[gcvit {tag}] feat rel_rms_err={frms:.3e} | logit max_abs_err={ze:.3e} logit mean={z_ref.mean().item():.3f} "
+           f"std={z_ref.std().item():.3f}")
+    return frms, ze, z_ref
+
+
+def test_gcvit_shallow(report):
+    """depths (2,2,2,2): every layer type incl. local + global-query attention at all four levels."""
+    cfg = dict(ref.NAME2CONFIG["gcvit_tiny"], depths=(2, 2, 2, 2))
+    frms, ze, z_ref = _run(cfg, 2, report, "d2222")
+    assert frms < 5e-3
+    assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())
+
+
+def test_gcvit_tiny_full(report):
+    frms, ze, z_ref = _run(ref.NAME2CONFIG["gcvit_tiny"], 4, report, "tiny")
+    assert frms < 5e-3
+    assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())

@@ -1,0 +1,201 @@
+"""GCViT on the HIP operator set — host-side mirror of the reference package models/gcvit
+(``GCViT`` models/gcvit.py:45-118, ``GCViTTiny`` :151-160, layers/{embedding,feature,level,block,attention}.py).
+
+Layout notes: activations stay plain NHWC feature maps for the whole network; ``window_partition`` /
+``window_reverse`` (layers/window.py:3-15) never materialise — the attention kernel addresses windows
+inside the feature map, and the Dense layers around it are row-wise so they do not care.
+"""
+from typing import Dict
+
+import torch
+
+from . import ops
+from .synth import ParamGen
+
+# models/gcvit/models/gcvit.py:10-43
+NAME2CONFIG = {
+    "gcvit_xxtiny": dict(window_size=(7, 7, 14, 7), dim=64, depths=(2, 2, 6, 2), num_heads=(2, 4, 8, 16), mlp_ratio=3.0),
+    "gcvit_xtiny": dict(window_size=(7, 7, 14, 7), dim=64, depths=(3, 4, 6, 5), num_heads=(2, 4, 8, 16), mlp_ratio=3.0),
+    "gcvit_tiny": dict(window_size=(7, 7, 14, 7), dim=64, depths=(3, 4, 19, 5), num_heads=(2, 4, 8, 16), mlp_ratio=3.0),
+}
+KEEP_DIMS = [(False, False, False), (False, False), (True,), (True,)]  # models/gcvit.py:71
+LN_EPS = 1e-5
+PAD1 = (1, 1, 1, 1)
+
+
+def synth_params(cfg: Dict, seed: int = 1002, classes: int = 1) -> Dict[str, torch.Tensor]:
+    g = ParamGen(seed)
+    dim = cfg["dim"]
+
+    def conv_branch(name, c):
+        g.dwconv(f"{name}/conv/0", 3, c, gain=1.0)
+        g.dense(f"{name}/conv/2/fc/0", c, int(c * 0.25), bias=False, gain=2.0)
+        g.dense(f"{name}/conv/2/fc/2", int(c * 0.25), c, bias=False)
+        g.conv(f"{name}/conv/3", 1, 1, c, c, gain=0.5)
+
+    def reduce_size(name, c, keep_dim):
+        g.ln(f"{name}/norm1", c)
+        conv_branch(name, c)
+        co = c if keep_dim else 2 * c
+        g.conv(f"{name}/reduction", 3, 3, c, co, gain=1.0)
+        g.ln(f"{name}/norm2", co)
+
+    g.conv("patch_embed/proj", 3, 3, 3, dim, bias=True, gain=1.0)
+    reduce_size("patch_embed/conv_down", dim, True)
+    c = dim
+    n = len(cfg["depths"])
+    for i in range(n):
+        ws, heads = cfg["window_size"][i], cfg["num_heads"][i]
+        for k, _ in enumerate(KEEP_DIMS[i]):
+            conv_branch(f"levels/{i}/q_global_gen/to_q_global/{k}", c)
+        for j in range(cfg["depths"][i]):
+            b = f"levels/{i}/blocks/{j}"
+            g.ln(f"{b}/norm1", c)
+            g.dense(f"{b}/attn/qkv", c, c * (2 if j % 2 else 3))
+            g.trunc_normal(f"{b}/attn/relative_position_bias_table", ((2 * ws - 1) ** 2, heads), 0.5)
+            g.dense(f"{b}/attn/proj", c, c, gain=0.25)
+            g.ln(f"{b}/norm2", c)
+            g.dense(f"{b}/mlp/fc1", c, int(c * cfg["mlp_ratio"]), gain=2.0)
+            g.dense(f"{b}/mlp/fc2", int(c * cfg["mlp_ratio"]), c, gain=0.25)
+        if i < n - 1:
+            reduce_size(f"levels/{i}/downsample", c, False)
+            c *= 2
+    g.ln("norm", c)
+    g.dense("head", c, classes)
+    return g.p
+
+
+class _ConvBranch:
+    """pad1 -> DWConv3x3 -> gelu -> SE -> Conv1x1 (+ residual), feature.py:90-98 / :130-138"""
+
+    def __init__(self, p, name, dev):
+        self.dw = p[f"{name}/conv/0/depthwise_kernel"][..., 0].to(dev, torch.float16).contiguous()
+        self.fc0 = ops.make_dense_weight(p[f"{name}/conv/2/fc/0/kernel"], None, dev)
+        self.fc2 = ops.make_dense_weight(p[f"{name}/conv/2/fc/2/kernel"], None, dev)
+        self.pw = ops.make_conv_weight(p[f"{name}/conv/3/kernel"], None, device=dev)
+
+    def __call__(self, x):
+        """returns x + branch(x)"""
+        y = ops.dwconv2d(x, self.dw, None, 3, 1, PAD1, act="gelu")
+        s = ops.global_avgpool(y)
+        s = ops.dense(s, self.fc0, act="gelu")
+        s = ops.dense(s, self.fc2, act="sigmoid")
+        y = ops.scale_add_act(y, s, None, None)
+        return ops.conv2d(y, self.pw, residual=x)
+
+
+class _LN:
+    def __init__(self, p, name, dev):
+        self.g = p[f"{name}/gamma"].to(dev, torch.float32).contiguous()
+        self.b = p[f"{name}/beta"].to(dev, torch.float32).contiguous()
+
+    def __call__(self, x):
+        return ops.layernorm(x, self.g, self.b, LN_EPS)
+
+
+class _ReduceSize:
+    """ReduceSize (feature.py:81-113)"""
+
+    def __init__(self, p, name, dev):
+        self.n1 = _LN(p, f"{name}/norm1", dev)
+        self.n2 = _LN(p, f"{name}/norm2", dev)
+        self.branch = _ConvBranch(p, name, dev)
+        self.red = ops.make_conv_weight(p[f"{name}/reduction/kernel"], None, device=dev)
+
+    def __call__(self, x, stride=2):
+        x = self.branch(self.n1(x))
+        return self.n2(ops.conv2d(x, self.red, stride=stride, pad=PAD1))
+
+
+class _Block:
+    """GCViTBlock (block.py:10-81) with WindowAttention (attention.py:7-83) and Mlp (feature.py:8-33)"""
+
+    def __init__(self, p, name, ws, heads, global_query, dev):
+        self.ws, self.heads, self.global_query = ws, heads, global_query
+        self.n1 = _LN(p, f"{name}/norm1", dev)
+        self.n2 = _LN(p, f"{name}/norm2", dev)
+        self.qkv = ops.make_dense_weight(p[f"{name}/attn/qkv/kernel"], p[f"{name}/attn/qkv/bias"], dev)
+        self.proj = ops.make_dense_weight(p[f"{name}/attn/proj/kernel"], p[f"{name}/attn/proj/bias"], dev)
+        self.table = p[f"{name}/attn/relative_position_bias_table"].to(dev, torch.float32).contiguous()
+        self.fc1 = ops.make_dense_weight(p[f"{name}/mlp/fc1/kernel"], p[f"{name}/mlp/fc1/bias"], dev)
+        self.fc2 = ops.make_dense_weight(p[f"{name}/mlp/fc2/kernel"], p[f"{name}/mlp/fc2/bias"], dev)
+
+    def __call__(self, x, q_global):
+        C = x.shape[-1]
+        hd = C // self.heads
+        qkv = ops.dense(self.n1(x), self.qkv)
+        att = ops.window_attention(qkv, q_global if self.global_query else None, self.table, self.heads, self.ws,
+                                   hd ** -0.5)
+        x = ops.dense(att, self.proj, residual=x)            # x + attn   (gamma1 = 1, block.py:54-56,79)
+        h = ops.dense(self.n2(x), self.fc1, act="gelu")
+        return ops.dense(h, self.fc2, residual=x)            # x + mlp    (:80)
+
+
+class GCViT:
+    def __init__(self, params: Dict[str, torch.Tensor], window_size, dim, depths, num_heads, mlp_ratio=3.0,
+                 classes: int = 1, device="cuda"):
+        p, dev = params, device
+        self.cfg = dict(window_size=window_size, dim=dim, depths=depths, num_heads=num_heads, mlp_ratio=mlp_ratio)
+        self.classes = classes
+        self.stem = ops.make_conv_weight(p["patch_embed/proj/kernel"], p["patch_embed/proj/bias"], device=dev,
+                                         pad_cin_to=8)
+        self.stem_down = _ReduceSize(p, "patch_embed/conv_down", dev)
+        self.levels = []
+        n = len(depths)
+        for i in range(n):
+            lv = {
+                "ws": window_size[i],
+                "qgen": [(_ConvBranch(p, f"levels/{i}/q_global_gen/to_q_global/{k}", dev), kd)
+                         for k, kd in enumerate(KEEP_DIMS[i])],
+                "blocks": [_Block(p, f"levels/{i}/blocks/{j}", window_size[i], num_heads[i], bool(j % 2), dev)
+                           for j in range(depths[i])],
+                "down": _ReduceSize(p, f"levels/{i}/downsample", dev) if i < n - 1 else None,
+            }
+            self.levels.append(lv)
+        self.norm = _LN(p, "norm", dev)
+        self.head_w = p["head/kernel"].t().contiguous().to(dev, torch.float32)
+        self.head_b = p["head/bias"].to(dev, torch.float32)
+
+    def _level(self, x, lv):
+        """GCViTLevel.call (level.py:46-67)"""
+        ws = lv["ws"]
+        B, H, W, C = x.shape
+        if H % ws or W % ws:
+            # FitWindow (feature.py:240-249) pads both sides; level.py:61 crops [:H,:W] afterwards
+            raise NotImplementedError("GCViT feature map not a multiple of the window: FitWindow padding not built yet")
+        qg = x
+        for branch, keep_dim in lv["qgen"]:
+            qg = branch(qg)
+            if not keep_dim:
+                qg = ops.pool2d(qg, 3, 2, PAD1, ops.POOL_MAX_ZEROPAD)
+        qg = qg.reshape(B, ws * ws, C)
+        for blk in lv["blocks"]:
+            x = blk(x, qg)
+        if lv["down"] is not None:
+            x = lv["down"](x)
+        return x
+
+    def features(self, x, collect=None):
+        """x: fp16 NHWC, RGB padded to 8 channels.  GCViT.forward_features (models/gcvit.py:98-105)."""
+        assert x.shape[-1] == 8
+        y = ops.conv2d(x, self.stem, stride=2, pad=PAD1)
+        y = self.stem_down(y)
+        if collect is not None:
+            collect.append(y)
+        for lv in self.levels:
+            y = self._level(y, lv)
+            if collect is not None:
+                collect.append(y)
+        return self.norm(y)
+
+    def logits(self, x):
+        return ops.gap_dense_f32(self.features(x), self.head_w, self.head_b)
+
+    def predict(self, x):
+        z = self.logits(x)
+        return torch.sigmoid(z) if self.classes == 1 else torch.softmax(z, dim=-1)
+
+
+def GCViTTiny(params, classes=1, device="cuda"):
+    """models/gcvit.py:151-160"""
+    return GCViT(params, **NAME2CONFIG["gcvit_tiny"], classes=classes, device=device)

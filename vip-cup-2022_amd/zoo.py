@@ -7,7 +7,7 @@ seeded synthetic checkpoint (synth.py); ``params`` dictionaries use the referenc
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Tuple
 
-from . import resnet_rs
+from . import gcvit, resnet_rs
 
 
 @dataclass
@@ -26,10 +26,13 @@ MEMBERS: Dict[str, MemberSpec] = {
     "resnet_rs50": MemberSpec("resnet_rs50", "ResNetRS50-200x200", 200, 1006,
                               lambda seed: resnet_rs.synth_params(50, seed),
                               lambda p: resnet_rs.ResNetRS50(p), "resnet_rs_ref", 3.790),
+    "gcvit_tiny": MemberSpec("gcvit_tiny", "GCViTTiny-224x224", 224, 1002,
+                             lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_tiny"], seed),
+                             lambda p: gcvit.GCViTTiny(p), "gcvit_ref", 4.760),
 }
 
 # order of ckpts/ckpts.json:2-8 (members are appended here as their graphs land)
-ENSEMBLE: List[str] = ["resnet_rs50"]
+ENSEMBLE: List[str] = ["gcvit_tiny", "resnet_rs50"]
 
 
 def build_member(name: str, seed: int = None) -> Tuple[MemberSpec, object]:
