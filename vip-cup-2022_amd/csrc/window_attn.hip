@@ -3,18 +3,26 @@
 //  folded into the addressing — qkv and out are plain [B,Hp,Wp,*] feature maps).
 //
 // Work item = (image, window, head), head_dim = 32.  ws=7: one wave per item, 4 items per workgroup;
-// ws=14: four waves share one item (K/V staged once, query tiles split over the waves).
+// ws=14: four waves share one item (K/V staged once, the 13 query tiles are dealt round-robin).
+// The kernel is HBM-bound by design (intensity N/2 FLOP/B); its job is to keep enough independent
+// workgroups resident per CU (<= 128 registers, <= 40 KB LDS) that staging, softmax VALU work and MFMA
+// of different workgroups overlap.
 //
 // Tokens are re-indexed on the way into LDS as row' = ty*P + tx with P = 8 (ws 7) or 16 (ws 14), so
-//   * 49 -> 64 rows (2 MFMA tiles of 32), 196 -> 224 rows (7 tiles) and
+//   * 49 -> 64 key rows, 196 -> 224 key rows (MFMA tiles of 16) and
 //   * the relative-position index (dy+ws-1)*(2ws-1) + (dx+ws-1) becomes, on a [2ws-1][2P] LDS copy of
-//     the head's bias table, base(query, lane-half) + a COMPILE-TIME constant per accumulator register:
-//     one ds_read_b32 with an immediate offset per score, no index arithmetic; padded key columns are
+//     the head's bias table, base(query, lane-group) + a COMPILE-TIME constant per accumulator register:
+//     one LDS read with an immediate offset per score, no index arithmetic; padded key slots are
 //     redirected to a block of -1e30 by swapping the base register.
 //
-// Math: S^T = K Q^T with v_mfma_f32_32x32x16_f16 (keys on rows, queries on the lane), so the softmax
-// over keys is register-local plus one lane^32 exchange, the probabilities are already the B operand of
-// O^T = V^T P^T, V^T fragments come from ds_read_b64_tr_b16, and the 1/rowsum is lane-local.
+// Math, per 16-query tile: S^T = K Q^T with v_mfma_f32_16x16x32_f16 (keys on rows, queries on the
+// lane: the whole head_dim is one MFMA), so the softmax over keys is register-local plus two cross-lane
+// exchanges, the probabilities are already the B operand of O^T = V^T P^T, V^T fragments come from
+// ds_read_b64_tr_b16, and the 1/rowsum is lane-local.  Q fragments are loaded straight from global.
+//
+// LDS images (64-byte rows, no padding): K chunk c of row r at slot c ^ pi[(r>>2)&3], pi = {0,2,3,1}
+// (conflict-free ds_read_b128 fragment reads); V 32-byte halves swapped on rows with bit 2 set
+// (conflict-free transposed reads).
 #include "common.hpp"
 
 namespace {
@@ -32,37 +40,43 @@ struct WinArgs {
     float scale_log2e;
 };
 
-template <int WS, int P, int LOG2P, int NT, int WPI>
+template <int WS, int P, int LOG2P, int WPI>
 struct WinCfg {
-    static constexpr int RP = NT * 32;
+    static constexpr int RP = (WS * P + 31) / 32 * 32;  // key rows (64 / 224)
+    static constexpr int NKT = RP / 16;                 // 16-key tiles
+    static constexpr int NQT = (WS * WS + 15) / 16;     // 16-query tiles over the DENSE token order (4 / 13)
     static constexpr int IPW = 4 / WPI;
-    static constexpr int QK_STRIDE = 80;  // bytes: 64 B of data + 16 B pad (conflict-free ds_read_b128)
-    static constexpr int V_STRIDE = 64;   // bytes: unpadded (conflict-free ds_read_b64_tr_b16)
-    static constexpr int KCMAX = 2 * (RP - 1);
-    static constexpr int NEGSZ = KCMAX + 2;
+    static constexpr int ROWB = 64;
+    static constexpr int KCMAX = 32 * NKT;
+    static constexpr int NEGSZ = KCMAX + 4;
     static constexpr int TOFF = NEGSZ + KCMAX;
     static constexpr int TROWS = 2 * WS - 1;
     static constexpr int TW = 2 * P;
     static constexpr int TB_FLOATS = TOFF + TROWS * TW;
-    static constexpr int Q_OFF = 0;
-    static constexpr int K_OFF = RP * QK_STRIDE;
-    static constexpr int V_OFF = 2 * RP * QK_STRIDE;
-    static constexpr int T_OFF = V_OFF + RP * V_STRIDE;
+    static constexpr int K_OFF = 0;
+    static constexpr int V_OFF = RP * ROWB;
+    static constexpr int T_OFF = 2 * RP * ROWB;
     static constexpr int ITEM_BYTES = (T_OFF + TB_FLOATS * 4 + 15) / 16 * 16;
     static constexpr int SMEM = ITEM_BYTES * IPW;
+    static constexpr int QPW = (NQT + WPI - 1) / WPI;   // query tiles per wave
 };
 
-template <int WS, int P, int LOG2P, int NT, int WPI>
-__global__ __launch_bounds__(256) void window_attn_kernel(WinArgs a) {
-    using Cfg = WinCfg<WS, P, LOG2P, NT, WPI>;
-    constexpr int RP = Cfg::RP;
+__device__ __forceinline__ int k_slot(int row, int ch) {
+    const int q = (row >> 2) & 3;
+    return ch ^ ((0x78 >> (q * 2)) & 3);  // pi = {0,2,3,1}
+}
+
+template <int WS, int P, int LOG2P, int WPI>
+__global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
+    using Cfg = WinCfg<WS, P, LOG2P, WPI>;
+    constexpr int RP = Cfg::RP, NKT = Cfg::NKT, NQT = Cfg::NQT, QPW = Cfg::QPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int slot = wave / WPI;            // item slot inside the workgroup
-    const int lt = tid - slot * WPI * 64;   // thread index inside the item's thread group
+    const int slot = wave / WPI;
+    const int lt = tid - slot * WPI * 64;
     int item = blockIdx.x * Cfg::IPW + slot;
     const bool item_ok = item < a.items;
     if (!item_ok) item = a.items - 1;
@@ -74,167 +88,204 @@ __global__ __launch_bounds__(256) void window_attn_kernel(WinArgs a) {
     const int b = wq / a.nWy;
 
     char* base = smem + slot * Cfg::ITEM_BYTES;
-    char* q_lds = base + Cfg::Q_OFF;
     char* k_lds = base + Cfg::K_OFF;
     char* v_lds = base + Cfg::V_OFF;
     float* tb = reinterpret_cast<float*>(base + Cfg::T_OFF);
 
-    // ---- stage q / k / v (re-indexed, zero-padded) and the head's bias table -------------------
     const int ldq = a.nq * a.C;
     const long img_pix = (long)b * a.Hp * a.Wp;
-    for (int s = lt; s < 3 * RP * 4; s += WPI * 64) {
-        const int arr = s / (RP * 4);
-        const int rem = s - arr * (RP * 4);
-        const int row = rem >> 2, ch = rem & 3;
-        const int ty = row >> LOG2P, tx = row & (P - 1);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (ty < WS && tx < WS) {
-            const long pix = img_pix + (long)(wy * WS + ty) * a.Wp + (wx * WS + tx);
-            const f16* src;
-            if (arr == 0) {
-                src = (a.nq == 3) ? a.qkv + pix * ldq + head * 32 + ch * 8
-                                  : a.qg + ((long)b * WS * WS + ty * WS + tx) * a.C + head * 32 + ch * 8;
-            } else {
-                src = a.qkv + pix * ldq + (a.nq - 3 + arr) * a.C + head * 32 + ch * 8;
-            }
-            v = *reinterpret_cast<const uint4*>(src);
-        }
-        char* dst = (arr == 0) ? q_lds + row * Cfg::QK_STRIDE
-                               : (arr == 1 ? k_lds + row * Cfg::QK_STRIDE : v_lds + row * Cfg::V_STRIDE);
-        *reinterpret_cast<uint4*>(dst + ch * 16) = v;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wi = wave % WPI;
+
+    // ---- Q fragments of this wave's query tiles, straight from global (issued first: longest latency) ----
+    U4H8 qf[QPW];
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) {
+        const int qn = (wi + i * WPI) * 16 + l15;  // dense token index ty*WS + tx
+        const int qy = qn / WS, qx = qn - qy * WS;
+        const bool valid = qn < WS * WS;
+        const long pix = img_pix + (long)(wy * WS + qy) * a.Wp + (wx * WS + qx);
+        const f16* src = (a.nq == 2) ? a.qg + ((long)b * WS * WS + qy * WS + qx) * a.C + head * 32 + g * 8
+                                     : a.qkv + pix * ldq + head * 32 + g * 8;
+        src = valid ? src : a.qkv;
+        const uint4 v = *reinterpret_cast<const uint4*>(src);
+        qf[i].u = valid ? v : make_uint4(0, 0, 0, 0);
     }
-    for (int i = lt; i < Cfg::TB_FLOATS; i += WPI * 64) {
-        float v = -1.0e30f;
-        if (i >= Cfg::TOFF) {
+
+    // ---- stage K / V (re-indexed, zero-padded, swizzled) and the head's bias table.  All global loads
+    // are UNCONDITIONAL (masked lanes read a safe address and are zeroed afterwards) and issued back to
+    // back before the first LDS write: a load inside an `if` costs a full memory round trip each. ----
+    constexpr int NSLOT = 2 * RP * 4, NTHR = WPI * 64, NIT = (NSLOT + NTHR - 1) / NTHR;
+    {
+        uint4 st[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int s = lt + it * NTHR;
+            const int arr = s / (RP * 4);  // 0 = K, 1 = V
+            const int rem = s - arr * (RP * 4);
+            const int row = rem >> 2, ch = rem & 3;
+            const int ty = row >> LOG2P, tx = row & (P - 1);
+            const bool valid = (s < NSLOT) & (ty < WS) & (tx < WS);
+            const long pix = img_pix + (long)(wy * WS + ty) * a.Wp + (wx * WS + tx);
+            const f16* src = a.qkv + pix * ldq + (a.nq - 2 + arr) * a.C + head * 32 + ch * 8;
+            src = valid ? src : a.qkv;
+            const uint4 v = *reinterpret_cast<const uint4*>(src);
+            st[it] = valid ? v : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int s = lt + it * NTHR;
+            const int arr = s / (RP * 4);
+            const int rem = s - arr * (RP * 4);
+            const int row = rem >> 2, ch = rem & 3;
+            if (s < NSLOT) {
+                const int pch = (arr == 0) ? k_slot(row, ch) : (ch ^ (((row >> 2) & 1) << 1));
+                *reinterpret_cast<uint4*>((arr == 0 ? k_lds : v_lds) + row * Cfg::ROWB + pch * 16) = st[it];
+            }
+        }
+    }
+    {
+        constexpr int TIT = (Cfg::TB_FLOATS + NTHR - 1) / NTHR;
+        float tv[TIT];
+#pragma unroll
+        for (int it = 0; it < TIT; ++it) {
+            const int i = lt + it * NTHR;
             const int e = i - Cfg::TOFF;
             const int ry = e / Cfg::TW, rx = e - ry * Cfg::TW;
-            v = (rx < Cfg::TROWS) ? a.table[(long)(ry * Cfg::TROWS + rx) * a.heads + head] * 1.44269504088896f : 0.f;
+            const bool in_tab = (i >= Cfg::TOFF) & (i < Cfg::TB_FLOATS) & (rx < Cfg::TROWS);
+            const int gi = in_tab ? (ry * Cfg::TROWS + rx) * a.heads + head : 0;
+            const float t = a.table[gi];
+            tv[it] = in_tab ? t * 1.44269504088896f : (i < Cfg::TOFF ? -1.0e30f : 0.f);
         }
-        tb[i] = v;
+#pragma unroll
+        for (int it = 0; it < TIT; ++it) {
+            const int i = lt + it * NTHR;
+            if (i < Cfg::TB_FLOATS) tb[i] = tv[it];
+        }
     }
     __syncthreads();
 
-    const int l31 = lane & 31, h = lane >> 5;
-    const int wi = wave % WPI;
     const float sc = a.scale_log2e;
+    // lane-dependent part of the key term 2k' - kx  (k' = 16t + 4g + r)
+    const int lane_term = (P == 16) ? 4 * g : 8 * g - 4 * (g & 1);
+    // LDS byte offsets of this lane's fragment reads
+    const int tr_q = l15 >> 2, tr_p = l15 & 3;
 
-#pragma unroll 1
-    for (int qt = wi; qt < NT; qt += WPI) {
-        const int qrow = qt * 32 + l31;
-        U4H8 qf[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-            qf[t].u = *reinterpret_cast<const uint4*>(q_lds + qrow * Cfg::QK_STRIDE + (16 * t + 8 * h) * 2);
+    for (int i = 0; i < QPW; ++i) {
+        const int qt = wi + i * WPI;
+        if (qt >= NQT) break;  // wave-uniform
+        const int qn = qt * 16 + l15;
 
-        // S^T tiles: rows = keys kt*32.., cols = this lane's query
-        f32x16 acc[NT];
+        // S^T tiles: rows = keys 16t + 4g + r, column = this lane's query
+        f32x4 acc[NKT];
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                U4H8 kf;
-                kf.u = *reinterpret_cast<const uint4*>(k_lds + (kt * 32 + l31) * Cfg::QK_STRIDE + (16 * t + 8 * h) * 2);
-                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf.h, qf[t].h, acc[kt], 0, 0, 0);
-            }
+        for (int t = 0; t < NKT; ++t) {
+            const int row = t * 16 + l15;
+            U4H8 kf;
+            kf.u = *reinterpret_cast<const uint4*>(k_lds + row * Cfg::ROWB + k_slot(row, g) * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf.h, qf[i].h, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
 
         // scale + relative-position bias (+ key padding mask), running max
-        const int qy = qrow >> LOG2P, qx = qrow & (P - 1);
-        const int qyc = qy < WS ? qy : WS - 1, qxc = qx < WS ? qx : WS - 1;
-        const int bidx = Cfg::TOFF + qyc * Cfg::TW + qxc + (WS - 1) * (Cfg::TW + 1) - 4 * h - Cfg::KCMAX;
-        const float* tbase = tb + bidx;
-        const float* tmask = h ? tb : tbase;
+        const int qy = qn / WS, qx = qn - qy * WS;
+        const int qyc = qy < WS ? qy : WS - 1, qxc = qx;
+        const float* tbase = tb + (Cfg::TOFF + qyc * Cfg::TW + qxc + (WS - 1) * (Cfg::TW + 1) - lane_term - Cfg::KCMAX);
         float m = -1.0e30f;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+        for (int t = 0; t < NKT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                constexpr int dummy = 0;
-                (void)dummy;
-                const int c = (r & 3) + 8 * (r >> 2);
-                const int kp = kt * 32 + c;           // key row' without the 4*h term
-                const int kyc = kp >> LOG2P;          // 4*h never carries into ty
-                const int kxc = c & (P - 1);
+            for (int r = 0; r < 4; ++r) {
+                // which lane groups g hold a padded key slot in register (t, r)?  (compile-time 4-bit mask)
+                int mask = 0;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int kp = 16 * t + 4 * gg + r;
+                    if (((kp & (P - 1)) >= WS) || ((kp >> LOG2P) >= WS)) mask |= 1 << gg;
+                }
                 float s;
-                if (kyc >= WS) {
+                if (mask == 15) {
                     s = -1.0e30f;
                 } else {
-                    const int imm = Cfg::KCMAX - (2 * kp - kxc);
-                    const float bias = (kxc + 4 >= WS) ? tmask[imm] : tbase[imm];
-                    s = acc[kt][r] * sc + bias;
+                    const int imm = Cfg::KCMAX - (32 * t + r);
+                    const float* bp = (mask == 0) ? tbase : (((mask >> g) & 1) ? tb : tbase);
+                    s = acc[t][r] * sc + bp[imm];
                 }
-                acc[kt][r] = s;
+                acc[t][r] = s;
                 m = fmaxf(m, s);
             }
         }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         float lsum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+        for (int t = 0; t < NKT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(acc[kt][r] - m);
-                acc[kt][r] = p;
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(acc[t][r] - m);
+                acc[t][r] = p;
                 lsum += p;
             }
         }
+        lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
 
-        // O^T = V^T P^T : A = V^T via transposed LDS reads, B = P^T straight from the accumulators
-        f32x16 o;
+        // O^T = V^T P^T : A = V^T (two 16-wide head-dim tiles) via transposed LDS reads, B = P^T from the
+        // accumulators: MFMA k-slot (g, j) carries key 32s + 4g + j (j < 4) / 32s + 16 + 4g + (j-4).
+        f32x4 o[2];
+        o[0] = o[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-        const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = (lane >> 4) & 1;
-        const char* vlane = v_lds + (4 * h + tr_q) * Cfg::V_STRIDE + (16 * tr_g + 4 * tr_p) * 2;
+        for (int s = 0; s < NKT / 2; ++s) {
+            U4H8 pf;
 #pragma unroll
-        for (int kt = 0; kt < NT; ++kt) {
+            for (int j = 0; j < 4; ++j) {
+                pf.e[j] = (f16)acc[2 * s][j];
+                pf.e[4 + j] = (f16)acc[2 * s + 1][j];
+            }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                U4H8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf.e[j] = (f16)acc[kt][8 * s + j];
-                const char* vp = vlane + (kt * 32 + 16 * s) * Cfg::V_STRIDE;
+            for (int dt = 0; dt < 2; ++dt) {
                 union {
                     fp16x4_t t[2];
                     f16x8 v;
                 } vf;
-                vf.t[0] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                    (__attribute__((address_space(3))) fp16x4_t*)(vp));
-                vf.t[1] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                    (__attribute__((address_space(3))) fp16x4_t*)(vp + 8 * Cfg::V_STRIDE));
-                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf.v, pf.h, o, 0, 0, 0);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int row = 32 * s + 16 * hh + 4 * g + tr_q;
+                    const int half = dt ^ ((row >> 2) & 1);  // = dt ^ (g & 1): 32-byte halves swapped on odd row quads
+                    vf.t[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                        (__attribute__((address_space(3))) fp16x4_t*)(v_lds + row * Cfg::ROWB + half * 32 + tr_p * 8));
+                }
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf.v, pf.h, o[dt], 0, 0, 0);
             }
         }
 
-        // store: lane owns query qrow, head-dim d = 8g + 4h + (0..3)
-        if (item_ok && qy < WS && qx < WS) {
+        // store: lane owns query qn, head-dim d = 16*dt + 4g + (0..3)
+        if (item_ok && qn < WS * WS) {
             const float inv = 1.f / lsum;
             const long pix = img_pix + (long)(wy * WS + qy) * a.Wp + (wx * WS + qx);
-            f16* dst = a.out + pix * a.C + head * 32 + 4 * h;
+            f16* dst = a.out + pix * a.C + head * 32 + 4 * g;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int dt = 0; dt < 2; ++dt) {
                 f16x4 ov;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) ov[i] = (f16)(o[4 * g + i] * inv);
-                *reinterpret_cast<f16x4*>(dst + 8 * g) = ov;
+                for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[dt][r] * inv);
+                *reinterpret_cast<f16x4*>(dst + 16 * dt) = ov;
             }
         }
     }
 }
 
-template <int WS, int P, int LOG2P, int NT, int WPI>
+template <int WS, int P, int LOG2P, int WPI>
 int launch_win(const WinArgs& a, hipStream_t s) {
-    using Cfg = WinCfg<WS, P, LOG2P, NT, WPI>;
+    using Cfg = WinCfg<WS, P, LOG2P, WPI>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel<WS, P, LOG2P, NT, WPI>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_kernel<WS, P, LOG2P, WPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
         attr_set = true;
     }
     const int wgs = (a.items + Cfg::IPW - 1) / Cfg::IPW;
-    hipLaunchKernelGGL((window_attn_kernel<WS, P, LOG2P, NT, WPI>), dim3(wgs), dim3(256), Cfg::SMEM, s, a);
+    hipLaunchKernelGGL((window_attn_kernel<WS, P, LOG2P, WPI>), dim3(wgs), dim3(256), Cfg::SMEM, s, a);
     return vip_launch_status("vip_window_attn_fwd_f16");
 }
 
@@ -260,6 +311,6 @@ extern "C" int vip_window_attn_fwd_f16(const void* qkv, const void* q_global, co
     VIP_REQUIRE(items < (1L << 30), VIP_ERR_UNSUPPORTED, "vip_window_attn_fwd_f16: too many windows");
     a.items = (int)items;
     a.scale_log2e = scale * 1.44269504088896f;
-    if (ws == 7) return launch_win<7, 8, 3, 2, 1>(a, (hipStream_t)stream);
-    return launch_win<14, 16, 4, 7, 4>(a, (hipStream_t)stream);
+    if (ws == 7) return launch_win<7, 8, 3, 1>(a, (hipStream_t)stream);
+    return launch_win<14, 16, 4, 4>(a, (hipStream_t)stream);
 }
