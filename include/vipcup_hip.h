@@ -141,6 +141,18 @@ int vip_window_attn_fwd_f16(const void* qkv, const void* q_global, const float* 
                             void* out, int B, int Hp, int Wp, int C, int heads, int ws, int nq,
                             float scale, void* stream);
 
+/* Plain multi-head self-attention core (tfimm/architectures/vit.py:148-167):
+ * out = softmax(scale * q k^T) v per (image, head).  qkv [B,N,3*D] f16 (channels = (q|k|v, head, hd));
+ * out [B,N,D].  head_dim = D/heads must be 64, N <= 224. */
+int vip_mhsa_fwd_f16(const void* qkv, void* out, int B, int N, int D, int heads, float scale,
+                     void* stream);
+
+/* ViT token assembly (tfimm/architectures/vit.py:419-426): out[b,0,:] = cls_token + pos_embed[0];
+ * out[b,1+i,:] = patches[b,i,:] + pos_embed[1+i].  patches [B,n_patches,D], cls [D], pos [n_patches+1,D],
+ * out [B,n_patches+1,D], all f16. */
+int vip_vit_tokens_f16(const void* patches, const void* cls_token, const void* pos_embed, void* out,
+                       int B, int n_patches, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,6 +48,8 @@ SIGNATURES = {
     "vip_gap_dense_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vip_scale_add_act_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_window_attn_fwd_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _vp]),
+    "vip_mhsa_fwd_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "vip_vit_tokens_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 

@@ -288,3 +288,26 @@ def to_device_nhwc8(x_nhwc3: torch.Tensor, device="cuda") -> torch.Tensor:
     out = torch.zeros((B, H, W, 8), dtype=torch.float16, device=device)
     out[..., :Cc] = x_nhwc3.to(device=device, dtype=torch.float16)
     return out
+
+
+def vit_tokens(patches, cls_token, pos_embed):
+    """[B,NP,D] patches + cls [D] + pos [NP+1,D] -> [B,NP+1,D] (tfimm vit.py:419-426)."""
+    _chk16(patches, "vit_tokens.patches")
+    B, NP, D = patches.shape
+    assert cls_token.numel() == D and pos_embed.numel() == (NP + 1) * D
+    out = torch.empty((B, NP + 1, D), dtype=torch.float16, device=patches.device)
+    st = _abi.lib().vip_vit_tokens_f16(_p(patches), _p(cls_token), _p(pos_embed), _p(out), B, NP, D, _stream())
+    _abi.check(st, "vip_vit_tokens_f16")
+    return out
+
+
+def cls_dense_f32(tokens, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Dense head on token 0 of ``[B,N,D]`` (ViT ``head(norm(x)[:, 0])``) -> fp32 ``[B,classes]``."""
+    _chk16(tokens, "cls_dense_f32.tokens")
+    B, N, D = tokens.shape
+    n_out = w_nc.shape[0]
+    assert w_nc.dtype == torch.float32 and w_nc.shape == (n_out, D) and w_nc.is_contiguous()
+    out = torch.empty((B, n_out), dtype=torch.float32, device=tokens.device)
+    st = _abi.lib().vip_gap_dense_f32(_p(tokens), _p(w_nc), _p(bias), _p(out), B, 1, D, N * D, n_out, _stream())
+    _abi.check(st, "vip_gap_dense_f32")
+    return out

@@ -7,7 +7,7 @@ seeded synthetic checkpoint (synth.py); ``params`` dictionaries use the referenc
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Tuple
 
-from . import gcvit, resnet_rs
+from . import gcvit, resnet_rs, tfimm_models as tm
 
 
 @dataclass
@@ -29,10 +29,23 @@ MEMBERS: Dict[str, MemberSpec] = {
     "gcvit_tiny": MemberSpec("gcvit_tiny", "GCViTTiny-224x224", 224, 1002,
                              lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_tiny"], seed),
                              lambda p: gcvit.GCViTTiny(p), "gcvit_ref", 4.760),
+    "convnext_tiny_in22k": MemberSpec("convnext_tiny_in22k", "convnext_tiny_in22k-200x200", 200, 1000,
+                                      lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_tiny_in22k"], seed),
+                                      lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_tiny_in22k"]),
+                                      "tfimm_ref", 13.33),
+    "vit_tiny_patch16_224": MemberSpec("vit_tiny_patch16_224", "vit_tiny_patch16_224-224x224", 224, 1008,
+                                       lambda seed: tm.vit_synth_params(tm.VIT_CONFIGS["vit_tiny_patch16_224"], seed),
+                                       lambda p: tm.ViT(p, tm.VIT_CONFIGS["vit_tiny_patch16_224"]), "tfimm_ref", 1.253),
+    "vit_small_patch16_224": MemberSpec("vit_small_patch16_224", "vit_small_patch16_224-224x224", 224, 1007,
+                                        lambda seed: tm.vit_synth_params(tm.VIT_CONFIGS["vit_small_patch16_224"], seed),
+                                        lambda p: tm.ViT(p, tm.VIT_CONFIGS["vit_small_patch16_224"]), "tfimm_ref", 4.598),
+    "vit_base_patch16_224": MemberSpec("vit_base_patch16_224", "vit_base_patch16_224-224x224", 224, 1009,
+                                       lambda seed: tm.vit_synth_params(tm.VIT_CONFIGS["vit_base_patch16_224"], seed),
+                                       lambda p: tm.ViT(p, tm.VIT_CONFIGS["vit_base_patch16_224"]), "tfimm_ref", 17.56),
 }
 
 # order of ckpts/ckpts.json:2-8 (members are appended here as their graphs land)
-ENSEMBLE: List[str] = ["gcvit_tiny", "resnet_rs50"]
+ENSEMBLE: List[str] = ["convnext_tiny_in22k", "gcvit_tiny", "resnet_rs50", "vit_small_patch16_224"]
 
 
 def build_member(name: str, seed: int = None) -> Tuple[MemberSpec, object]:
