@@ -153,6 +153,57 @@ int vip_mhsa_fwd_f16(const void* qkv, void* out, int B, int N, int D, int heads,
 int vip_vit_tokens_f16(const void* patches, const void* cls_token, const void* pos_embed, void* out,
                        int B, int n_patches, int D, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline (dataset/dataset.py:22-39): decode_jpeg -> cast f32 -> bicubic resize -> /255,
+ * and the TTA ops of dataset/augment.py:115-120,142-146.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vip_jpeg_desc {
+    int32_t width, height;            /* image size                                             */
+    int32_t ncomp;                    /* 1 or 3                                                 */
+    int32_t hsamp[3], vsamp[3];       /* sampling factors                                       */
+    int32_t blocks_w[3], blocks_h[3]; /* coefficient-plane size in 8x8 blocks (padded to MCUs)  */
+    int64_t coef_off[3];              /* offset (int16 elements) of each component's blocks     */
+    uint16_t qt[3][64];               /* dequantisation tables, natural (row-major) order       */
+} vip_jpeg_desc;
+
+/* Host: parse headers only (fills the descriptor; coef_off relative to 0) and report how many int16
+ * coefficients the image needs. */
+int vip_jpeg_probe_h(const uint8_t* jpeg_h, size_t len, vip_jpeg_desc* desc_h, size_t* coef_elems_h);
+
+/* Host, multithreaded: baseline-sequential Huffman decode (ITU-T T.81 Annex F) of n JPEG byte streams into
+ * quantised DCT coefficients (natural order, int16, block-major per component) packed back to back in
+ * coef_h; desc_h[i].coef_off are offsets into coef_h.  Replaces the entropy-decoding half of
+ * tf.image.decode_jpeg (dataset/dataset.py:28).  Progressive / arithmetic / 12-bit / CMYK -> VIP_ERR_JPEG. */
+int vip_jpeg_entropy_decode_h(const uint8_t* const* jpeg_h, const size_t* len_h, int n,
+                              vip_jpeg_desc* desc_h, int16_t* coef_h, size_t coef_cap,
+                              size_t* coef_used_h, int threads);
+
+/* Device: dequantise + 8x8 ISLOW IDCT (libjpeg jidctint.c) into component planes (planes_ws: one byte per
+ * coefficient, same offsets), then h2v1/h2v2/h1v2 "fancy" chroma upsampling (jdsample.c) + YCbCr->RGB
+ * (jdcolor.c): the same uint8 pixels as libjpeg-turbo, the decoder inside tf.image.decode_jpeg.
+ * coef/desc are DEVICE copies of what vip_jpeg_entropy_decode_h produced; max_blocks = the largest
+ * per-image block count (all components); rgb_u8 [n][maxH][maxW][3] (pixels beyond an image's size are
+ * left untouched). */
+int vip_jpeg_idct_rgb_u8(const int16_t* coef, const vip_jpeg_desc* desc, int n, int max_blocks,
+                         uint8_t* planes_ws, uint8_t* rgb_u8, int maxH, int maxW, void* stream);
+
+/* Host: the 1025x2 coefficient table of TensorFlow's legacy bicubic kernel (Keys a = -0.5). */
+int vip_bicubic_table_f32(float* table_h);
+
+/* Device: uint8 RGB -> float -> bicubic resize (Keys a=-0.5, half-pixel centres, offset quantised to the
+ * 1024-entry table, out-of-image taps dropped and weights renormalised = tf.image.resize(method="bicubic",
+ * antialias=False)) -> /255 -> f16 NHWC with the channel axis zero-padded to c_out.
+ * Replaces dataset/dataset.py:31-38.  sizes_hw int32 [n][2] = (h,w) of each image inside its
+ * maxH x maxW slot; table = device copy of vip_bicubic_table_f32. */
+int vip_resize_bicubic_norm_f16(const uint8_t* rgb_u8, const int32_t* sizes_hw, const float* table,
+                                int n, int maxH, int maxW, void* out, int outH, int outW, int c_out,
+                                void* stream);
+
+/* TTA ops (dataset/augment.py:115-120,142-146) on f16 NHWC batches: flags int32 [B]: bit0 horizontal flip,
+ * bit1 vertical flip, bit2 RGB->gray->RGB (0.2989, 0.5870, 0.1140). */
+int vip_tta_augment_f16(const void* x, void* y, const int32_t* flags, int B, int H, int W, int C,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,54 +142,72 @@ _TABLE_SIZE = 1024
 
 
 def _bicubic_table():
+    """InitCoeffsTable(a = -0.5) of TensorFlow's resize_bicubic_op.cc: evaluated in double, stored as float."""
     a = -0.5
-    t = torch.zeros((_TABLE_SIZE + 1) * 2, dtype=torch.float32)
+    t = torch.zeros((_TABLE_SIZE + 1) * 2, dtype=torch.float64)
     for i in range(_TABLE_SIZE + 1):
-        x = torch.tensor(i / _TABLE_SIZE, dtype=torch.float32)
+        x = i * 1.0 / _TABLE_SIZE
         t[i * 2] = ((a + 2) * x - (a + 3)) * x * x + 1
-        x = x + 1.0
+        x += 1.0
         t[i * 2 + 1] = ((a * x - 5 * a) * x + 8 * a) * x - 4 * a
-    return t
+    return t.to(torch.float32)
 
 
 _TABLE = None
 
 
 def bicubic_weights_and_indices(out_size, in_size):
-    """Per output coordinate: 4 source indices (clamped) and 4 fp32 weights."""
+    """Per output coordinate: 4 source indices (clamped) and 4 fp32 weights (GetWeightsAndIndices with
+    HalfPixelScaler, use_keys_cubic=True: out-of-image taps get weight 0, then renormalise)."""
     global _TABLE
     if _TABLE is None:
         _TABLE = _bicubic_table()
-    scale = torch.tensor(in_size / out_size, dtype=torch.float32)
+    f32 = torch.float32
+    scale = torch.tensor(in_size, dtype=f32) / torch.tensor(out_size, dtype=f32)
     idx = torch.zeros((out_size, 4), dtype=torch.long)
-    wts = torch.zeros((out_size, 4), dtype=torch.float32)
+    wts = torch.zeros((out_size, 4), dtype=f32)
     for o in range(out_size):
-        in_loc_f = (torch.tensor(o, dtype=torch.float32) + 0.5) * scale - 0.5
-        in_loc = int(torch.floor(in_loc_f))
-        delta = in_loc_f - in_loc
+        in_loc_f = (torch.tensor(o, dtype=f32) + 0.5) * scale - 0.5
+        fl = torch.floor(in_loc_f)
+        in_loc = int(fl)
+        delta = in_loc_f - fl
         offset = int(torch.round(delta * _TABLE_SIZE))  # lrintf: round-half-even, same as torch.round
         w = [_TABLE[offset * 2 + 1], _TABLE[offset * 2], _TABLE[(_TABLE_SIZE - offset) * 2],
              _TABLE[(_TABLE_SIZE - offset) * 2 + 1]]
+        s = torch.tensor(0.0, dtype=f32)
         for t in range(4):
             want = in_loc - 1 + t
             got = min(max(want, 0), in_size - 1)
             idx[o, t] = got
             wts[o, t] = w[t] if got == want else 0.0
-        s = wts[o].sum()
+            s = s + wts[o, t]
         if abs(float(s)) >= 1000.0 * 1.17549435e-38:
-            wts[o] = wts[o] * (torch.tensor(1.0, dtype=torch.float32) / s)
+            wts[o] = wts[o] * (torch.tensor(1.0, dtype=f32) / s)
     return idx, wts
 
 
 def resize_bicubic(img_hwc, out_h, out_w):
-    """float32 [H,W,C] -> [out_h,out_w,C], no clamping (values may overshoot [0,255])."""
+    """float32 [H,W,C] -> [out_h,out_w,C], no clamping (values may overshoot [0,255]).  Interpolate1D order:
+    ((v0*w0 + v1*w1) + v2*w2) + v3*w3, first along x on the four source rows, then along y."""
     H, W, _ = img_hwc.shape
     iy, wy = bicubic_weights_and_indices(out_h, H)
     ix, wx = bicubic_weights_and_indices(out_w, W)
-    # the TF kernel interpolates along x first, then along y (both fp32)
-    rows = (img_hwc[:, ix, :] * wx[None, :, :, None]).sum(dim=2)  # [H,out_w,C]
-    out = (rows[iy, :, :] * wy[:, :, None, None]).sum(dim=1)      # [out_h,out_w,C]
+    rows = None
+    for t in range(4):
+        term = img_hwc[:, ix[:, t], :] * wx[None, :, t, None]          # [H,out_w,C]
+        rows = term if rows is None else rows + term
+    out = None
+    for t in range(4):
+        term = rows[iy[:, t], :, :] * wy[:, t, None, None]             # [out_h,out_w,C]
+        out = term if out is None else out + term
     return out
+
+
+def decode_resize_normalize(rgb_u8_hwc, out_h, out_w):
+    """build_decoder.decode after the JPEG decode (dataset/dataset.py:31-38): cast f32 -> resize (always
+    taken: `img_size != (200, 200)` compares a list with a tuple) -> /255."""
+    img = torch.as_tensor(rgb_u8_hwc).to(torch.float32)
+    return resize_bicubic(img, out_h, out_w) / 255.0
 
 
 # ---------------------------------------------------------------------------------------------

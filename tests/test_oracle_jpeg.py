@@ -1,0 +1,90 @@
+"""CPU: (1) pin the JPEG oracle to libjpeg-turbo (Pillow) on the reference's own fixture images and on the
+synthetic set; (2) check the product's HOST entropy decoder (C++ in libvipcup_hip.so, no GPU needed)
+against the oracle's coefficients."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import jpeg_ref
+from tools.make_synth import synth_jpeg, synth_pixels
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _variants():
+    """extra encodings of one synthetic image: 4:2:2, grayscale, restart markers, odd sizes"""
+    px = synth_pixels(7)
+    out = {}
+    for name, kw in {"s422": dict(subsampling=1), "q30_420": dict(quality=30, subsampling=2),
+                     "q100_444": dict(quality=100, subsampling=0)}.items():
+        b = io.BytesIO()
+        Image.fromarray(px).save(b, format="JPEG", **{"quality": 85, **kw})
+        out[name] = b.getvalue()
+    b = io.BytesIO()
+    Image.fromarray(px).convert("L").save(b, format="JPEG", quality=80)
+    out["gray"] = b.getvalue()
+    b = io.BytesIO()
+    Image.fromarray(px[:173, :131]).save(b, format="JPEG", quality=75, subsampling=2)
+    out["odd_173x131_420"] = b.getvalue()
+    b = io.BytesIO()
+    Image.fromarray(px[:57, :200]).save(b, format="JPEG", quality=75, subsampling=1, restart_marker_blocks=3)
+    out["restart_422"] = b.getvalue()
+    return out
+
+
+def _pil(b):
+    return np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))
+
+
+@pytest.mark.parametrize("name", ["dog_cat", "cat", "dog"])
+def test_oracle_matches_pillow_on_reference_fixtures(name):
+    """the three JPEGs embedded in the reference (kecam test_images.py:6-15)"""
+    raw = open(os.path.join(GOLD, f"ref_{name}.jpg"), "rb").read()
+    stats = json.load(open(os.path.join(GOLD, "ref_jpeg_pillow_stats.json")))[name]
+    got = jpeg_ref.decode_rgb(raw)
+    assert list(got.shape) == stats["shape"]
+    assert int(got.astype(np.int64).sum()) == stats["sum"]          # committed Pillow statistic
+    assert [int(got[r].astype(np.int64).sum()) for r in (0, 100, 255, 511)] == stats["crc_rows"]
+    assert np.array_equal(got, _pil(raw))                            # and the live library
+
+
+def test_oracle_matches_pillow_on_synthetic_set():
+    for i in list(range(8)) + [49]:
+        raw = synth_jpeg(i)
+        assert np.array_equal(jpeg_ref.decode_rgb(raw), _pil(raw)), i
+    for name, raw in _variants().items():
+        assert np.array_equal(jpeg_ref.decode_rgb(raw), _pil(raw)), name
+
+
+def test_host_entropy_decoder_matches_oracle():
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import pipeline
+    raws = [synth_jpeg(i) for i in (0, 1, 49)] + list(_variants().values())
+    raws.append(open(os.path.join(GOLD, "ref_cat.jpg"), "rb").read())
+    desc, coef = pipeline.entropy_decode(raws, threads=3)
+    for i, raw in enumerate(raws):
+        P = jpeg_ref.parse(raw)
+        ref_coefs, _ = jpeg_ref.entropy_decode(P)
+        d = desc[i]
+        assert (d.height, d.width, d.ncomp) == (P["h"], P["w"], len(P["comp"]))
+        for c, rc in enumerate(ref_coefs):
+            n = rc.size
+            got = coef[d.coef_off[c]:d.coef_off[c] + n].reshape(rc.shape)
+            assert (d.blocks_h[c], d.blocks_w[c]) == rc.shape[:2]
+            assert np.array_equal(got.astype(np.int64), rc), (i, c)
+            assert np.array_equal(np.array(d.qt[c][:], dtype=np.int64), P["qt"][P["comp"][c]["tq"]])
+
+
+def test_unsupported_streams_are_rejected():
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import _abi, pipeline
+    b = io.BytesIO()
+    Image.fromarray(synth_pixels(3)).save(b, format="JPEG", quality=80, progressive=True)
+    with pytest.raises(_abi.VipError):
+        pipeline.entropy_decode([b.getvalue()])
+    with pytest.raises(_abi.VipError):
+        pipeline.entropy_decode([b"not a jpeg at all"])

@@ -49,6 +49,12 @@ SIGNATURES = {
     "vip_scale_add_act_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_window_attn_fwd_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _vp]),
     "vip_mhsa_fwd_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "vip_jpeg_probe_h": (_i, [_vp, _sz, _vp, _vp]),
+    "vip_jpeg_entropy_decode_h": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp, _i]),
+    "vip_jpeg_idct_rgb_u8": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "vip_bicubic_table_f32": (_i, [_vp]),
+    "vip_resize_bicubic_norm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "vip_tta_augment_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_vit_tokens_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 
