@@ -125,6 +125,11 @@ int vip_gap_dense_f32(const void* x, const float* W, const float* bias, float* o
 int vip_scale_add_act_f16(const void* x, const void* scale, const void* residual, void* y,
                           int B, int HW, int C, int act, void* stream);
 
+/* ResNeSt split-attention combine (kecam resnest/resnest.py:57-61): out[b,p,c] = sum_r x[b,p,r*C+c] *
+ * scale[b,r*C+c].  x f16 [B,HW,radix*C]; scale f16 [B,radix*C] (the r-softmax weights); out [B,HW,C]. */
+int vip_radix_combine_f16(const void* x, const void* scale, void* y, int B, int HW, int C, int radix,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * GCViT window attention core (gcvit/layers/attention.py:52-83, window.py:3-15):
  *   out = softmax( (q*scale) k^T + rel_bias ) v     per (image, window, head)

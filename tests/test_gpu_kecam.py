@@ -1,0 +1,49 @@
+"""GPU parity of the four kecam members (ResNest50, EfficientNetV2T, EfficientNetV1B4, ECA_NFNetL0)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import kecam_ref as ref  # noqa: E402
+from tests.test_gpu_resnet_rs import _images  # noqa: E402
+from tests.test_gpu_ops import check, dev, h  # noqa: E402
+
+
+def test_radix_combine(report):
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = h(torch.randn(2, 5, 6, 128, generator=g))
+    s = h(torch.rand(2, 128, generator=g))
+    refv = (x * s[:, None, None, :]).reshape(2, 5, 6, 2, 64).sum(3)
+    check(report, "radix_combine", ops.radix_combine(dev(x), dev(s), 2), refv)
+
+
+@pytest.mark.parametrize("key", ["resnest50", "efficientnet_v2t", "efficientnet_v1b4", "eca_nfnet_l0"])
+def test_kecam_member(key, report):
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ops, zoo
+    spec = zoo.MEMBERS[key]
+    p = spec.synth(spec.seed)
+    x = _images(3, spec.input_hw).to(torch.float16).to(torch.float32)
+    ca, cb = [], []
+    with torch.no_grad():
+        ref.features(key, p, x, collect=ca)
+        z_ref = ref.predict_logits(key, p, x)
+    m = spec.ctor(p)
+    xd = ops.to_device_nhwc8(x)
+    m.features(xd, collect=cb)
+    z = m.logits(xd).cpu()
+    torch.cuda.synchronize()
+    assert len(ca) == len(cb)
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(ca, cb)):
+        b = b.float().cpu()
+        assert a.shape == b.shape, (i, a.shape, b.shape)
+        rel = ((a - b) ** 2).mean().sqrt().item() / a.pow(2).mean().sqrt().item()
+        worst = max(worst, rel)
+        report(f"[{key}] stage {i} shape {tuple(a.shape)} ref_rms {a.pow(2).mean().sqrt().item():.3f} rel_rms_err {rel:.3e}")
+    ze = (z - z_ref).abs().max().item()
+    report(f"[{key}] logit max_abs_err={ze:.3e} logit mean={z_ref.mean().item():.3f} std={z_ref.std().item():.3f}")
+    assert worst < 6e-3
+    assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())

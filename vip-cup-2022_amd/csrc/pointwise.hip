@@ -383,3 +383,42 @@ extern "C" int vip_gap_dense_f32(const void* x, const float* W, const float* bia
                        C, ldx, N);
     return vip_launch_status("vip_gap_dense_f32");
 }
+
+// ---------------------------------------------------------------------------------------------
+// ResNeSt split-attention combine (kecam resnest/resnest.py:57-61): out[b,p,c] = sum_r x[b,p,r*C+c] * s[b,r*C+c]
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void radix_combine_kernel(const f16* __restrict__ x, const f16* __restrict__ s,
+                                                            f16* __restrict__ y, long total8, int HW, int C8, int radix) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        const long pix = idx / C8;
+        const int b = (int)(pix / HW);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int r = 0; r < radix; ++r) {
+            U4H8 v, w;
+            v.u = *reinterpret_cast<const uint4*>(x + (pix * radix * C8 + (long)r * C8 + c8) * 8);
+            w.u = *reinterpret_cast<const uint4*>(s + (((long)b * radix + r) * C8 + c8) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v.e[j] * (float)w.e[j];
+        }
+        U4H8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = (f16)acc[j];
+        *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
+    }
+}
+}  // namespace
+
+extern "C" int vip_radix_combine_f16(const void* x, const void* scale, void* y, int B, int HW, int C, int radix,
+                                     void* stream) {
+    VIP_REQUIRE(x && scale && y, VIP_ERR_BAD_ARG, "vip_radix_combine_f16: null pointer");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && radix > 0, VIP_ERR_BAD_ARG, "vip_radix_combine_f16: non-positive dimension");
+    VIP_REQUIRE(C % 8 == 0, VIP_ERR_ALIGNMENT, "vip_radix_combine_f16: C must be a multiple of 8");
+    const long total8 = (long)B * HW * (C / 8);
+    hipLaunchKernelGGL(radix_combine_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
+                       (const f16*)scale, (f16*)y, total8, HW, C / 8, radix);
+    return vip_launch_status("vip_radix_combine_f16");
+}

@@ -1,0 +1,105 @@
+"""Ensemble scoring — the MI355X counterpart of ``predict_soln`` (main.py:58-149).
+
+Reference flow per model: rebuild the dataset (re-decoding every JPEG), ``model.predict`` in batches of 128,
+mean over TTA (:111), multi-class -> binary ``1 - p[:,0]`` (:113-114), mean over folds (:121); then across
+models: concat, ``groupby(filename).mean()`` (:142-143), ``(mean > thr) * 1.0`` (:144), CSV (:145).
+
+Here: each batch of files is decoded ONCE, every member consumes the resident pixels at its own resolution,
+and with N > 1 processes the IMAGES are sharded across ranks (every rank holds all members — 175 M parameters
+are nothing next to 288 GB) with one all-gather of the per-image scores at the end (the only exchange step;
+SURVEY.md §8e).
+"""
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+THR = 0.487          # main.py:225
+REF_BATCH = 128      # 8 * NAME2BS.get(name, 16) for every shipped member (main.py:43-56,85)
+
+
+def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced image shard of rank ``rank``: sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def to_binary(pred: np.ndarray) -> np.ndarray:
+    """main.py:113-114: a multi-class head reports P(real) in column 0 -> P(synthetic) = 1 - p[:,0]"""
+    pred = np.asarray(pred, dtype=np.float32)
+    if pred.ndim == 1:
+        pred = pred[:, None]
+    return 1.0 - pred[:, 0:1] if pred.shape[1] > 1 else pred
+
+
+def aggregate(filenames: Sequence[str], per_model: np.ndarray, thr: float = THR):
+    """per_model ``[M, N]`` probabilities -> (sorted unique filenames, mean score, decision).
+    Mirrors concat + groupby('filename').mean() (rows sorted by filename, duplicates averaged) and the strict
+    ``> thr`` of main.py:142-144.  (The reference's own frame has a string-typed 'logit' column and fails on
+    current pandas; the evident intent — the arithmetic mean — is what is computed.)"""
+    names = np.asarray(filenames)
+    uniq, inv = np.unique(names, return_inverse=True)
+    mean_per_image = per_model.astype(np.float64).mean(axis=0)            # mean over models per row
+    sums = np.zeros(len(uniq), np.float64)
+    cnts = np.zeros(len(uniq), np.float64)
+    np.add.at(sums, inv, mean_per_image)
+    np.add.at(cnts, inv, 1.0)
+    score = (sums / cnts).astype(np.float32)
+    return uniq.tolist(), score, (score > thr).astype(np.float32)
+
+
+def all_gather_scores(local: torch.Tensor, counts: List[int], dist=None) -> torch.Tensor:
+    """The exchange step: every rank contributes ``[M, n_local]`` scores; returns ``[M, sum(counts)]`` in rank
+    order on every rank.  Shards are padded to the largest count so ONE all_gather (RCCL over xGMI on GPUs,
+    gloo in the CPU tests) moves everything."""
+    if dist is None or len(counts) == 1:
+        return local
+    M = local.shape[0]
+    width = max(counts)
+    pad = torch.zeros((M, width), dtype=local.dtype, device=local.device)
+    pad[:, :local.shape[1]] = local
+    out = torch.empty((len(counts) * M, width), dtype=local.dtype, device=local.device)  # concatenated along dim 0
+    dist.all_gather_into_tensor(out, pad)
+    out = out.view(len(counts), M, width)
+    return torch.cat([out[r, :, :c] for r, c in enumerate(counts)], dim=1)
+
+
+def score_files(jpegs_for: Callable[[int, int], List[bytes]], n_images: int, members: List[Tuple[object, object]],
+                batch_size: int = REF_BATCH, rank: int = 0, world: int = 1, dist=None,
+                scorer: Optional[Callable] = None) -> np.ndarray:
+    """Score images [0, n_images) with every member; returns ``[M, n_images]`` fp32 probabilities on every rank.
+
+    ``jpegs_for(lo, hi)`` returns the JPEG byte strings of images lo..hi-1 (read lazily, per batch).
+    ``members`` = [(spec, model)] with ``spec.input_hw`` and ``model.predict(x) -> [n, C]``.
+    ``scorer(raws, members) -> [M, n]`` replaces the GPU path in the CPU (gloo) tests."""
+    lo, hi = shard_bounds(n_images, rank, world)
+    counts = [shard_bounds(n_images, r, world)[1] - shard_bounds(n_images, r, world)[0] for r in range(world)]
+    chunks = []
+    for b0 in range(lo, hi, batch_size):
+        raws = jpegs_for(b0, min(b0 + batch_size, hi))
+        chunks.append(scorer(raws, members) if scorer is not None else _score_batch(raws, members))
+    M = len(members)
+    if chunks:
+        local = torch.cat(chunks, dim=1)
+    else:
+        dev = "cuda" if (scorer is None and torch.cuda.is_available()) else "cpu"
+        local = torch.zeros((M, 0), dtype=torch.float32, device=dev)
+    full = all_gather_scores(local, counts, dist)
+    return full.detach().float().cpu().numpy()
+
+
+def _score_batch(raws: List[bytes], members) -> torch.Tensor:
+    """decode once -> per member: resize to its resolution, predict, multi->binary.  Returns [M, n] (device)."""
+    from . import pipeline
+    batch = pipeline.decode_jpegs(raws)
+    cache: Dict[int, torch.Tensor] = {}
+    rows = []
+    for spec, model in members:
+        hw = spec.input_hw
+        if hw not in cache:
+            cache[hw] = batch.resized(hw, hw)
+        p = model.predict(cache[hw])                       # [n, C] fp32
+        p = (1.0 - p[:, 0]) if p.shape[1] > 1 else p[:, 0]  # main.py:113-114
+        rows.append(p.float())
+    return torch.stack(rows, 0)

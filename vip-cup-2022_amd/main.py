@@ -1,0 +1,114 @@
+"""Drop-in CLI for the reference entry point (main.py:151-235):
+
+    python3 vip-cup-2022_amd/main.py <input.csv> <output.csv> [--scores-out scores.csv] [--synthetic]
+    python -m torch.distributed.run --nproc-per-node N ... vip-cup-2022_amd/main.py in.csv out.csv
+
+Same contract: the input CSV has a ``filename`` column with paths relative to the CSV's directory (main.py:77-79,
+155-164); the output CSV has columns ``filename,logit`` with logit in {0.0, 1.0} = (ensemble mean > 0.487)
+(main.py:143-145,225).  ``--scores-out`` additionally writes the continuous ensemble mean (the reference keeps
+it only in memory).  The ensemble manifest is ``ckpts/ckpts.json`` ([name, [H,W], idx],
+main.py:171-198); members whose graph is not built yet are reported and skipped only under ``--allow-missing``.
+
+Checkpoints: ``<script dir>/ckpts/<name>/ckpt/*.npz`` (a flat dict of Keras-named arrays, one file per fold).
+The reference ships none (README.md:13) and raises when a directory is empty (main.py:194); so does this CLI,
+unless ``--synthetic`` asks for the seeded synthetic checkpoints.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from glob import glob
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("input_csv")
+    ap.add_argument("output_csv")
+    ap.add_argument("--scores-out", default=None)
+    ap.add_argument("--synthetic", action="store_true")
+    ap.add_argument("--allow-missing", action="store_true")
+    ap.add_argument("--ckpt-cfg", default=os.path.join(HERE, "ckpts", "ckpts.json"))
+    ap.add_argument("--batch-size", type=int, default=128)  # main.py:85
+    ap.add_argument("--debug", type=int, default=0)         # main.py:82-83: first 100 images
+    a = ap.parse_args(argv)
+
+    import pandas as pd
+    import torch
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ensemble, zoo
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("vipcup_amd main: no GPU visible — the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    infer_path = os.path.dirname(os.path.abspath(a.input_csv))   # main.py:161-164
+    test_csv = pd.read_csv(a.input_csv)
+    names = test_csv.filename.values.tolist()
+    if a.debug:
+        names = names[:100]
+    paths = [os.path.join(infer_path, n) for n in names]
+
+    members = []
+    for name, dim, idx in json.load(open(a.ckpt_cfg)):           # main.py:171-198
+        key = zoo.by_ckpt_name(name)
+        if key is None:
+            if a.allow_missing:
+                if rank == 0:
+                    print(f"> SKIP {name}: graph not built in this round")
+                continue
+            raise ValueError(f"manifest member {name} has no graph in vipcup_amd.zoo")
+        spec = zoo.MEMBERS[key]
+        assert [spec.input_hw, spec.input_hw] == list(dim), (name, dim)
+        ckpts = sorted(glob(os.path.join(HERE, "ckpts", name, "ckpt", "*.npz")))
+        if ckpts:
+            folds = [spec.ctor({k: torch.from_numpy(v) for k, v in np.load(c).items()}) for c in ckpts]
+        elif a.synthetic:
+            folds = [zoo.build_member(key)[1]]
+        else:
+            raise ValueError(f"no checkpoints under ckpts/{name}/ckpt (pass --synthetic for seeded synthetic weights)")
+        members.append((spec, zoo.FoldMean(folds)))                # mean over folds, main.py:121
+        if rank == 0:
+            print(f"> MODEL({len(members)}): {name} | DIM: {dim} | folds: {len(folds)}")
+
+    def jpegs_for(lo, hi):
+        out = []
+        for p in paths[lo:hi]:
+            with open(p, "rb") as f:
+                out.append(f.read())
+        return out
+
+    t0 = time.time()
+    per_model = ensemble.score_files(jpegs_for, len(paths), members, a.batch_size, rank, world, dist)
+    uniq, score, decision = ensemble.aggregate(names, per_model)
+    if rank == 0:
+        pd.DataFrame({"filename": uniq, "logit": decision}).to_csv(a.output_csv, index=False)  # main.py:143-145
+        if a.scores_out:
+            cols = {"filename": names, "ensemble_mean": per_model.mean(axis=0)}
+            for (spec, _), row in zip(members, per_model):
+                cols[spec.name] = row
+            pd.DataFrame(cols).to_csv(a.scores_out, index=False)
+        dt = time.time() - t0
+        print(f"> FINAL PREDICTION SAVED TO {a.output_csv}")
+        print(f"> TIME TO INFER: {dt / 60:.2f} min ({len(paths) / dt:.1f} images/s on {world} GPU(s))")  # main.py:231-235
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

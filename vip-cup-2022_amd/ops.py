@@ -311,3 +311,16 @@ def cls_dense_f32(tokens, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     st = _abi.lib().vip_gap_dense_f32(_p(tokens), _p(w_nc), _p(bias), _p(out), B, 1, D, N * D, n_out, _stream())
     _abi.check(st, "vip_gap_dense_f32")
     return out
+
+
+def radix_combine(x, scale, radix: int = 2):
+    """ResNeSt split-attention combine: x ``[B,H,W,radix*C]``, scale ``[B,radix*C]`` -> ``[B,H,W,C]``."""
+    _chk16(x, "radix_combine.x")
+    _chk16(scale, "radix_combine.scale")
+    B, H, W, RC = x.shape
+    Cc = RC // radix
+    assert scale.shape == (B, RC)
+    out = torch.empty((B, H, W, Cc), dtype=torch.float16, device=x.device)
+    st = _abi.lib().vip_radix_combine_f16(_p(x), _p(scale), _p(out), B, H * W, Cc, radix, _stream())
+    _abi.check(st, "vip_radix_combine_f16")
+    return out

@@ -7,7 +7,7 @@ seeded synthetic checkpoint (synth.py); ``params`` dictionaries use the referenc
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Tuple
 
-from . import gcvit, resnet_rs, tfimm_models as tm
+from . import gcvit, kecam_models as km, resnet_rs, tfimm_models as tm
 
 
 @dataclass
@@ -33,6 +33,16 @@ MEMBERS: Dict[str, MemberSpec] = {
                                       lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_tiny_in22k"], seed),
                                       lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_tiny_in22k"]),
                                       "tfimm_ref", 13.33),
+    "resnest50": MemberSpec("resnest50", "ResNest50-200x200", 200, 1001, lambda seed: km.resnest_synth_params(seed),
+                            lambda p: km.ResNest(p), "kecam_ref", 4.518),
+    "efficientnet_v2t": MemberSpec("efficientnet_v2t", "EfficientNetV2T-200x200", 200, 1003,
+                                   lambda seed: km.effnet_synth_params("EfficientNetV2T", seed),
+                                   lambda p: km.EfficientNet(p, "EfficientNetV2T"), "kecam_ref", 1.627),
+    "efficientnet_v1b4": MemberSpec("efficientnet_v1b4", "EfficientNetV1B4-224x224", 224, 1004,
+                                    lambda seed: km.effnet_synth_params("EfficientNetV1B4", seed),
+                                    lambda p: km.EfficientNet(p, "EfficientNetV1B4"), "kecam_ref", 1.502),
+    "eca_nfnet_l0": MemberSpec("eca_nfnet_l0", "ECA_NFNetL0-200x200", 200, 1005, lambda seed: km.nfnet_synth_params(seed),
+                               lambda p: km.NormFreeNet(p), "kecam_ref", 3.617),
     "vit_tiny_patch16_224": MemberSpec("vit_tiny_patch16_224", "vit_tiny_patch16_224-224x224", 224, 1008,
                                        lambda seed: tm.vit_synth_params(tm.VIT_CONFIGS["vit_tiny_patch16_224"], seed),
                                        lambda p: tm.ViT(p, tm.VIT_CONFIGS["vit_tiny_patch16_224"]), "tfimm_ref", 1.253),
@@ -45,10 +55,32 @@ MEMBERS: Dict[str, MemberSpec] = {
 }
 
 # order of ckpts/ckpts.json:2-8 (members are appended here as their graphs land)
-ENSEMBLE: List[str] = ["convnext_tiny_in22k", "gcvit_tiny", "resnet_rs50", "vit_small_patch16_224"]
+ENSEMBLE: List[str] = ["convnext_tiny_in22k", "resnest50", "gcvit_tiny", "efficientnet_v2t", "efficientnet_v1b4",
+                       "eca_nfnet_l0", "resnet_rs50"]
+# BASELINE.json config 5 asks for 8 members: the shipped 7 + a tfimm ViT
+ENSEMBLE8: List[str] = ENSEMBLE + ["vit_small_patch16_224"]
 
 
 def build_member(name: str, seed: int = None) -> Tuple[MemberSpec, object]:
     spec = MEMBERS[name]
     params = spec.synth(spec.seed if seed is None else seed)
     return spec, spec.ctor(params)
+
+
+def by_ckpt_name(ckpt_name: str):
+    """manifest directory name (ckpts/ckpts.json) -> registry key, or None if the graph is not built"""
+    for k, spec in MEMBERS.items():
+        if spec.ckpt_name == ckpt_name:
+            return k
+    return None
+
+
+class FoldMean:
+    """mean over the fold checkpoints of one member (main.py:101-121)"""
+
+    def __init__(self, folds):
+        self.folds = folds
+
+    def predict(self, x):
+        ps = [m.predict(x) for m in self.folds]
+        return ps[0] if len(ps) == 1 else sum(ps) / float(len(ps))
