@@ -1,0 +1,68 @@
+"""GPU end-to-end (BASELINE configs 1 & 4/5 in miniature): the drop-in CLI on a synthetic JPEG folder + CSV versus
+the oracle path (libjpeg-turbo decode -> oracle resize -> oracle models -> mean -> threshold)."""
+import importlib
+import io
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops_ref as R  # noqa: E402
+from tools.make_synth import synth_jpeg  # noqa: E402
+
+N_IMG = 16
+TOL_LOGIT = 1e-3   # BASELINE.json north_star: |z_hip - z_ref| <= 1e-3 on the sigmoid logit
+
+
+def _logit(p):
+    p = np.clip(p, 1e-7, 1 - 1e-7)
+    return np.log(p / (1 - p))
+
+
+def test_main_cli_matches_oracle(tmp_path, report):
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import main as cli, zoo
+    idx = list(range(100, 100 + N_IMG - 1)) + [149]          # includes one 256x192 image (resize branch)
+    names = []
+    for i in idx:
+        n = f"img_{i:05d}.jpg"
+        (tmp_path / n).write_bytes(synth_jpeg(i))
+        names.append(n)
+    (tmp_path / "test.csv").write_text("filename\n" + "\n".join(names) + "\n")
+    out_csv, scores_csv = tmp_path / "out.csv", tmp_path / "scores.csv"
+    cli.main([str(tmp_path / "test.csv"), str(out_csv), "--synthetic", "--scores-out", str(scores_csv), "--batch-size", "8"])
+    got = pd.read_csv(scores_csv)
+    dec = pd.read_csv(out_csv)
+    assert list(dec.columns) == ["filename", "logit"] and set(dec.logit.unique()) <= {0.0, 1.0}
+    assert dec.filename.tolist() == sorted(names)
+
+    # oracle path
+    pix = [np.asarray(Image.open(io.BytesIO(synth_jpeg(i))).convert("RGB")) for i in idx]
+    probs = {}
+    worst = 0.0
+    for key in zoo.ENSEMBLE:
+        spec = zoo.MEMBERS[key]
+        x = torch.stack([R.decode_resize_normalize(p, spec.input_hw, spec.input_hw) for p in pix])
+        ref = importlib.import_module(f"oracle.{spec.oracle}")
+        with torch.no_grad():
+            z = ref.predict_logits(key, zoo.build_params(key), x).numpy()[:, 0]
+        probs[key] = 1.0 / (1.0 + np.exp(-z))
+        dz = np.abs(_logit(got[key].values) - z)
+        worst = max(worst, dz.max())
+        report(f"[e2e] {key:22s} max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e}  z range [{z.min():+.2f},{z.max():+.2f}]")
+        assert dz.max() <= TOL_LOGIT, (key, dz.max())
+    mean_ref = np.mean([probs[k] for k in zoo.ENSEMBLE], axis=0)
+    dm = np.abs(got["ensemble_mean"].values - mean_ref).max()
+    report(f"[e2e] ensemble mean max|dp|={dm:.3e}; worst member |dz|={worst:.3e}")
+    assert dm <= TOL_LOGIT
+    # decisions (threshold 0.487, strict) — identical unless the oracle score sits within tolerance of the threshold
+    want = dict(zip(names, (mean_ref > 0.487).astype(np.float32)))
+    margin = dict(zip(names, np.abs(mean_ref - 0.487)))
+    flips = [n for n, v in zip(dec.filename, dec.logit) if v != want[n] and margin[n] > TOL_LOGIT]
+    report(f"[e2e] decisions: {int(dec.logit.sum())}/{len(dec)} positive, flips vs oracle: {len(flips)}")
+    assert not flips

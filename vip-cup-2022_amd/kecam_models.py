@@ -198,6 +198,7 @@ def _effnet_blocks(c):
 def effnet_synth_params(name: str, seed: int, classes: int = 1) -> Dict[str, torch.Tensor]:
     c = EFFNET[name]
     g = ParamGen(seed)
+    boost = all(se > 0 for se in c["se_ratios"])   # V1: every block is gated -> compensate (see below)
     stem = make_divisible(c["first_conv_filter"], 8)
     g.conv("stem_conv", 3, 3, 3, stem)
     g.bn("stem_bn", stem)
@@ -219,7 +220,8 @@ def effnet_synth_params(name: str, seed: int, classes: int = 1) -> Dict[str, tor
             g.conv(f"{n}fu_conv", 3, 3, hid, out)
             g.bn(f"{n}fu_bn", out)
         else:
-            g.conv(f"{n}MB_pw_conv", 1, 1, hid, out, gain=0.25 if sc else 1.0)
+            # the SE gate (~0.5) quarters the variance of the branch: compensate so the signal survives 30+ blocks
+            g.conv(f"{n}MB_pw_conv", 1, 1, hid, out, gain=(0.5 if sc else 4.0) if (red > 0 and boost) else (0.25 if sc else 1.0))
             g.bn(f"{n}MB_pw_bn", out)
         last = out
     post = make_divisible(c["output_conv_filter"], 8)
