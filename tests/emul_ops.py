@@ -1,0 +1,152 @@
+"""Test infrastructure: CPU emulation of vipcup_amd.ops on top of the oracle primitives, so the product's host
+graphs (with their FOLDED, fp16-rounded weights) can be executed in fp32 on the CPU.  Two knobs separate the
+error sources of the HIP path:  round_act  — round every op output to fp16 (what the kernels store);
+                                weights are always the product's fp16 tensors.
+Usage:  with emul_ops.patched(round_act=False): model = spec.ctor(params_on_cpu) ; model.logits(x8)"""
+import contextlib
+
+import torch
+
+from oracle import ops_ref as R
+
+ROUND_ACT = False
+ACTN = {0: None, 1: "relu", 2: "silu", 3: "gelu", 4: "sigmoid", None: None}
+
+
+def _r(t):
+    return t.to(torch.float16).to(torch.float32) if ROUND_ACT else t
+
+
+def _an(a):
+    return ACTN.get(a, a) if not isinstance(a, str) else a
+
+
+def _w(cw):
+    k = cw.kh * cw.kw * cw.cin_g
+    return cw.w.float()[:, :k].reshape(cw.cout, cw.kh, cw.kw, cw.cin_g).permute(1, 2, 3, 0)
+
+
+def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=None, out=None, cin_off=0, cout_off=0):
+    xx = x[..., cin_off:cin_off + cw.cin]
+    y = R.act(R.conv2d(xx, _w(cw), cw.bias, stride, pad, cw.groups), _an(act))
+    if residual is not None:
+        y = y + residual[..., :cw.cout]
+    y = _r(R.act(y, _an(act_post)))
+    if out is not None:
+        out[..., cout_off:cout_off + cw.cout] = y
+        return out
+    return y
+
+
+def dense(x, cw, act=None, act_post=None, residual=None):
+    y = R.act(x @ _w(cw)[0, 0] + (cw.bias if cw.bias is not None else 0), _an(act))
+    if residual is not None:
+        y = y + residual
+    return _r(R.act(y, _an(act_post)))
+
+
+def dwconv2d(x, w_khwc, bias, k, stride=1, pad=(0, 0, 0, 0), act=None):
+    return _r(R.act(R.dwconv2d(x, w_khwc.float()[..., None], bias, stride, pad), _an(act)))
+
+
+def layernorm(x, gamma, beta, eps):
+    return _r(R.layernorm(x, gamma, beta, eps))
+
+
+POOL_MAX_ZEROPAD, POOL_AVG_VALID, POOL_AVG_FULL = 0, 1, 2
+
+
+def pool2d(x, k, stride, pad=(0, 0, 0, 0), mode=0):
+    if mode == 0:
+        return _r(R.maxpool_valid(x, k, stride, pad))
+    if mode == 2:
+        return _r(R.avgpool_valid(x, k, stride, pad))
+    xp = R.zero_pad(x, pad).permute(0, 3, 1, 2)
+    ones = R.zero_pad(torch.ones_like(x[..., :1]), pad).permute(0, 3, 1, 2)
+    F = torch.nn.functional
+    return _r((F.avg_pool2d(xp, k, stride) / F.avg_pool2d(ones, k, stride)).permute(0, 2, 3, 1).contiguous())
+
+
+def global_avgpool(x):
+    B, C = x.shape[0], x.shape[-1]
+    return _r(x.reshape(B, -1, C).mean(1))
+
+
+def gap_dense_f32(x, w_nc, bias):
+    B, C = x.shape[0], x.shape[-1]
+    return x.reshape(B, -1, C).mean(1) @ w_nc.t() + (bias if bias is not None else 0)
+
+
+def cls_dense_f32(t, w_nc, bias):
+    return t[:, 0] @ w_nc.t() + (bias if bias is not None else 0)
+
+
+def scale_add_act(x, scale=None, residual=None, act=None):
+    y = x
+    if scale is not None:
+        y = y * scale.reshape(scale.shape[0], *([1] * (x.dim() - 2)), scale.shape[-1])
+    if residual is not None:
+        y = y + residual
+    return _r(R.act(y, _an(act)))
+
+
+def radix_combine(x, scale, radix=2):
+    B, H, W, RC = x.shape
+    return _r((x * scale[:, None, None, :]).reshape(B, H, W, radix, RC // radix).sum(3))
+
+
+def window_attention(qkv, q_global, table, heads, ws, scale):
+    from oracle import gcvit_ref
+    B, Hp, Wp, CC = qkv.shape
+    nq = 2 if q_global is not None else 3
+    C = CC // nq
+    hd = C // heads
+    win = R.window_partition(qkv, ws).reshape(-1, ws * ws, nq, heads, hd).permute(2, 0, 3, 1, 4)
+    B_ = win.shape[1]
+    if q_global is not None:
+        k, v = win[0], win[1]
+        q = torch.repeat_interleave(q_global.reshape(B, ws * ws, C), B_ // B, dim=0).reshape(B_, ws * ws, heads, hd).permute(0, 2, 1, 3)
+    else:
+        q, k, v = win[0], win[1], win[2]
+    o = gcvit_ref.window_attention_core(q, k, v, table, ws, scale)
+    return _r(R.window_reverse(o.permute(0, 2, 1, 3).reshape(B_, ws * ws, C), ws, Hp, Wp, C))
+
+
+def mhsa(qkv, heads, scale):
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    q, k, v = qkv.reshape(B, N, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+    attn = torch.softmax(scale * (q @ k.transpose(-1, -2)), dim=-1)
+    return _r((attn @ v).permute(0, 2, 1, 3).reshape(B, N, D))
+
+
+def vit_tokens(patches, cls, pos):
+    B = patches.shape[0]
+    return _r(torch.cat([cls.float().expand(B, 1, -1), patches], 1) + pos.float())
+
+
+def to_device_nhwc8(x, device="cpu"):
+    out = torch.zeros((*x.shape[:3], 8))
+    out[..., :3] = x.to(torch.float16).float()
+    return out
+
+
+@contextlib.contextmanager
+def patched(round_act=False):
+    """swap vipcup_amd.ops' compute entry points for the CPU emulation (weights builders stay the product's)"""
+    global ROUND_ACT
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ops
+    names = ["conv2d", "dense", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
+             "scale_add_act", "radix_combine", "window_attention", "mhsa", "vit_tokens", "to_device_nhwc8"]
+    saved = {n: getattr(ops, n) for n in names}
+    old = ROUND_ACT
+    ROUND_ACT = round_act
+    try:
+        for n in names:
+            setattr(ops, n, globals()[n])
+        yield
+    finally:
+        ROUND_ACT = old
+        for n, f in saved.items():
+            setattr(ops, n, f)

@@ -69,7 +69,7 @@ class _ConvBranch:
     """pad1 -> DWConv3x3 -> gelu -> SE -> Conv1x1 (+ residual), feature.py:90-98 / :130-138"""
 
     def __init__(self, p, name, dev):
-        self.dw = p[f"{name}/conv/0/depthwise_kernel"][..., 0].to(dev, torch.float16).contiguous()
+        self.dw = ops.make_dw_weight(p[f"{name}/conv/0/depthwise_kernel"], None, dev)
         self.fc0 = ops.make_dense_weight(p[f"{name}/conv/2/fc/0/kernel"], None, dev)
         self.fc2 = ops.make_dense_weight(p[f"{name}/conv/2/fc/2/kernel"], None, dev)
         self.pw = ops.make_conv_weight(p[f"{name}/conv/3/kernel"], None, device=dev)

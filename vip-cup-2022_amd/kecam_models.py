@@ -246,9 +246,8 @@ class EfficientNet(_Base):
                 blk["exp"] = _cbn(p, f"{n}sortcut_", f"{n}sortcut_", eps, dev)
             if not fused:
                 s_ = p[f"{n}MB_dw_bn/gamma"] / torch.sqrt(p[f"{n}MB_dw_bn/moving_variance"] + eps)
-                w = p[f"{n}MB_dw_/depthwise_kernel"][..., 0] * s_
                 b = p[f"{n}MB_dw_bn/beta"] - p[f"{n}MB_dw_bn/moving_mean"] * s_
-                blk["dw"] = (w.to(dev, torch.float16).contiguous(), b.to(dev, torch.float32).contiguous())
+                blk["dw"] = (ops.make_dw_weight(p[f"{n}MB_dw_/depthwise_kernel"], s_, dev), b.to(dev, torch.float32).contiguous())
             if red > 0:
                 blk["se"] = (ops.make_conv_weight(p[f"{n}se_1_conv/kernel"], p[f"{n}se_1_conv/bias"], device=dev,
                                                   pad_cout_to=_r8(red)),

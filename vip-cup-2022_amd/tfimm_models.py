@@ -190,7 +190,7 @@ class ConvNeXt:
                 gamma = p[f"{b}/gamma"]
                 # x*gamma folded into fc2: (W x + b) * gamma = (W*gamma) x + b*gamma  (convnext.py:226)
                 st["blocks"].append(dict(
-                    dw=p[f"{b}/conv_dw/depthwise_kernel"][..., 0].to(dev, torch.float16).contiguous(),
+                    dw=ops.make_dw_weight(p[f"{b}/conv_dw/depthwise_kernel"], None, dev),
                     dwb=p[f"{b}/conv_dw/bias"].to(dev, torch.float32).contiguous(),
                     norm=_LN(p, f"{b}/norm", dev),
                     fc1=ops.make_dense_weight(p[f"{b}/mlp/fc1/kernel"], p[f"{b}/mlp/fc1/bias"], dev),
