@@ -57,7 +57,7 @@ def cpu_baseline(wl, n_images):
     for name in wl.members:
         spec = zoo.MEMBERS[name]
         ref = importlib.import_module(f"oracle.{spec.oracle}")
-        params = spec.synth(spec.seed)
+        params = zoo.build_params(name)
         x = torch.rand((bs, spec.input_hw, spec.input_hw, 3), generator=g)
         with torch.no_grad():
             ref.predict_logits(name, params, x)  # discarded

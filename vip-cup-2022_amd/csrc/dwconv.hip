@@ -1,0 +1,171 @@
+// Depthwise convolution, stride 1, register-tiled: each thread owns a 4x4 patch of output pixels for 8
+// channels and walks the (4+K-1) input rows ONCE (one 16-byte load and one fp16->fp32 conversion per input
+// chunk, 6.25 loads per output chunk for K=7 instead of 17.5), with the K*K*C filter pre-converted to fp32 in
+// LDS (every lane of a channel chunk reads the same address: broadcast, conflict-free).
+// The op is VALU-bound on CDNA4 (49 FMAs per output element for the ConvNeXt 7x7 and no matrix-core mapping
+// for a per-channel filter), so the point of the structure is to spend the VALU on FMAs, not on conversions.
+// Replaces tf.keras.layers.DepthwiseConv2D (tfimm convnext.py:192-198; gcvit feature.py:93,133; kecam
+// efficientnet_v2.py:85) for stride 1; strided cases stay on the simple kernel of pointwise.hip.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int K, int TW>
+__global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+                                                             const float* __restrict__ bias, f16* __restrict__ y,
+                                                             int B, int H, int W, int C, int pt, int pl, int Ho,
+                                                             int Wo, int act, int cb_chunks, int tiles_x, int tiles_y,
+                                                             long n_tiles, long x_bytes) {
+    constexpr int T = 4;                 // output rows per thread
+    constexpr int P = T + K - 1;         // input patch rows
+    constexpr int PW = TW + K - 1;       // input patch columns (TW output columns per thread)
+    extern __shared__ __attribute__((aligned(16))) float wlds[];  // [K*K][cb_chunks*8] fp32
+
+    const int c8_0 = blockIdx.y * cb_chunks;               // first channel chunk of this block
+    const int C8 = C >> 3;
+    const int nch = min(cb_chunks, C8 - c8_0);              // chunks this block really has
+    // stage the filter slice as fp32
+    for (int i = threadIdx.x; i < K * K * nch * 8; i += 256) {
+        const int tap = i / (nch * 8), c = i - tap * (nch * 8);
+        wlds[tap * (cb_chunks * 8) + c] = (float)w[(long)tap * C + c8_0 * 8 + c];
+    }
+    __syncthreads();
+
+    const int tiles_per_block = 256 / cb_chunks;
+    const int lc = threadIdx.x % cb_chunks;                 // chunk inside the block (fastest: coalesced rows)
+    const int lt = threadIdx.x / cb_chunks;
+    const long tile = (long)blockIdx.x * tiles_per_block + lt;
+    if (lt >= tiles_per_block || tile >= n_tiles || lc >= nch) return;
+    const int tx = (int)(tile % tiles_x);
+    const int ty = (int)((tile / tiles_x) % tiles_y);
+    const int b = (int)(tile / ((long)tiles_x * tiles_y));
+    const int oy0 = ty * T, ox0 = tx * TW;
+    const int c0 = (c8_0 + lc) * 8;
+    const float* wl = wlds + lc * 8;
+
+    f32x2 acc[T][TW][4];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][j][q] = (f32x2){0.f, 0.f};
+
+    // buffer descriptor over the whole input: out-of-image taps use an out-of-range offset and read as zero in
+    // hardware (a `cond ? load : 0` in source makes hipcc predicate + serialise every load, see conv_igemm.hip)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)x_bytes, 0x00020000);
+    const unsigned xoff0 = (unsigned)((((long)b * H * W) * C + c0) * 2);
+    auto load_row = [&](int iy, uint4 (&raw)[PW]) {
+        const int gy = oy0 - pt + iy;
+        const bool row_ok = (unsigned)gy < (unsigned)H;
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            const int gx = ox0 - pl + q;
+            const bool ok = row_ok & ((unsigned)gx < (unsigned)W);
+            const unsigned off = ok ? xoff0 + (unsigned)((gy * W + gx) * C * 2) : 0xFFFFFFF0u;
+            raw[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+    };
+    uint4 raw[PW];
+    load_row(0, raw);
+    // NOT unrolled (unrolling makes hipcc hoist every load and spill); the NEXT row's loads are issued before the
+    // current row is converted and multiplied, so their latency hides under ~400 VALU instructions
+#pragma unroll 1
+    for (int iy = 0; iy < P; ++iy) {
+        uint4 nxt[PW];
+        load_row(iy + 1 < P ? iy + 1 : iy, nxt);
+        f32x2 xr[PW][4];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+            U4H8 v;
+            v.u = raw[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xr[q][e][0] = (float)v.e[2 * e];
+                xr[q][e][1] = (float)v.e[2 * e + 1];
+            }
+        }
+#pragma unroll
+        for (int oy = 0; oy < T; ++oy) {
+            const int r = iy - oy;                 // wave-uniform
+            if (r < 0 || r >= K) continue;
+            // weights of tap (r, s+1) are fetched from LDS before the FMAs of tap (r, s)
+            const float* wrow = wl + (r * K) * (cb_chunks * 8);
+            float4 w0 = *reinterpret_cast<const float4*>(wrow);
+            float4 w1 = *reinterpret_cast<const float4*>(wrow + 4);
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                const int sn = s + 1 < K ? s + 1 : s;
+                const float4 n0 = *reinterpret_cast<const float4*>(wrow + sn * (cb_chunks * 8));
+                const float4 n1 = *reinterpret_cast<const float4*>(wrow + sn * (cb_chunks * 8) + 4);
+                const f32x2 wv[4] = {{w0.x, w0.y}, {w0.z, w0.w}, {w1.x, w1.y}, {w1.z, w1.w}};
+#pragma unroll
+                for (int ox = 0; ox < TW; ++ox)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[oy][ox][e] = xr[ox + s][e] * wv[e] + acc[oy][ox][e];
+                w0 = n0;
+                w1 = n1;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PW; ++q) raw[q] = nxt[q];
+    }
+
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[c0 + j] : 0.f;
+#pragma unroll
+    for (int oy = 0; oy < T; ++oy) {
+        const int gy = oy0 + oy;
+        if (gy >= Ho) break;
+#pragma unroll
+        for (int ox = 0; ox < TW; ++ox) {
+            const int gx = ox0 + ox;
+            if (gx >= Wo) break;
+            U4H8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o.e[2 * e] = (f16)vip_act(acc[oy][ox][e][0] + bv[2 * e], act);
+                o.e[2 * e + 1] = (f16)vip_act(acc[oy][ox][e][1] + bv[2 * e + 1], act);
+            }
+            *reinterpret_cast<uint4*>(y + (((long)b * Ho + gy) * Wo + gx) * C + c0) = o.u;
+        }
+    }
+}
+
+template <int K, int TW>
+int launch_tile(const f16* x, const f16* w, const float* bias, f16* y, int B, int H, int W, int C, int pt, int pl,
+                int Ho, int Wo, int act, hipStream_t s) {
+    const int C8 = C / 8;
+    // channel chunks per block: a divisor-friendly width <= 16 chunks (128 channels) that wastes few lanes
+    int cb = C8 < 16 ? C8 : 16;
+    if (C8 % 12 == 0 && C8 % 16 != 0) cb = 12;                   // ConvNeXt widths 96/192/384/768
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + 3) / 4;
+    const long n_tiles = (long)B * tiles_x * tiles_y;
+    const int tiles_per_block = 256 / cb;
+    const long gx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    const int gyc = (C8 + cb - 1) / cb;
+    const size_t smem = (size_t)K * K * cb * 8 * sizeof(float);
+    hipLaunchKernelGGL((dwconv_tile_kernel<K, TW>), dim3((unsigned)gx, (unsigned)gyc), dim3(256), smem, s, x, w, bias, y, B,
+                       H, W, C, pt, pl, Ho, Wo, act, cb, tiles_x, tiles_y, n_tiles, 2L * B * H * W * C);
+    return vip_launch_status("vip_dwconv2d_nhwc_f16(tile)");
+}
+
+}  // namespace
+
+// stride-1 fast path; returns 1 if the shape is not handled here
+int vip_dwconv_tiled(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int k,
+                     int pt, int pl, int Ho, int Wo, int act, hipStream_t s) {
+    const f16* xi = (const f16*)x;
+    const f16* wi = (const f16*)w;
+    f16* yo = (f16*)y;
+    const long gx = ((long)B * ((Wo + 1) / 2) * ((Ho + 3) / 4) + 15) / 16;
+    if (gx >= (1L << 31) || 2L * B * H * W * C >= 0xFFFFFFF0L) return 1;
+    // tile widths chosen so that accumulators + one fp32 patch row stay well under 256 VGPRs (no scratch)
+    if (k == 3) return launch_tile<3, 4>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s);
+    if (k == 5) return launch_tile<5, 2>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s);
+    if (k == 7) return launch_tile<7, 2>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s);
+    return 1;
+}

@@ -316,6 +316,10 @@ extern "C" int vip_dwconv2d_nhwc_f16(const void* x, const void* w, const float* 
     const f16* xi = (const f16*)x;
     const f16* wi = (const f16*)w;
     f16* yo = (f16*)y;
+    if (stride == 1) {
+        const int st = vip_dwconv_tiled(x, w, bias, y, B, H, W, C, k, pt, pl, Ho, Wo, act, s);
+        if (st != 1) return st;
+    }
 #define VIP_DW(KK, SS, TW)                                                                                        \
     {                                                                                                             \
         const long total = (long)B * Ho * ((Wo + TW - 1) / TW) * C8;                                              \

@@ -7,10 +7,10 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import ops
+from . import ops, pipeline
 from . import zoo
 
-DEFAULT = "resnet_rs50"
+DEFAULT = "ensemble"
 
 
 class KernelProfile:
@@ -49,22 +49,24 @@ class Workload:
         self.world = world
         self.members = members
         self.models = [zoo.build_member(m) for m in members]
+        # resident input: decoded 200x200 RGB uint8 pixels (what tf.image.decode_jpeg yields, dataset.py:28)
         g = torch.Generator().manual_seed(1234 + rank)
-        self.inputs = {}
-        for spec, _ in self.models:
-            hw = spec.input_hw
-            if hw not in self.inputs:
-                x = torch.zeros((batch, hw, hw, 8), dtype=torch.float16, device="cuda")
-                x[..., :3] = torch.rand((batch, hw, hw, 3), generator=g).to(device="cuda", dtype=torch.float16)
-                self.inputs[hw] = x
+        rgb = torch.randint(0, 256, (batch, 200, 200, 3), generator=g, dtype=torch.uint8).cuda()
+        sizes = torch.tensor([[200, 200]] * batch, dtype=torch.int32, device="cuda")
+        self.batch_rgb = pipeline.DecodedBatch(rgb, sizes, [(200, 200)] * batch)
         self.scores = None
         self._gather = None
 
     def step(self, dist=None):
-        """Score the resident batch with every member; mean over members (main.py:142-143); all-gather."""
+        """cast+resize+/255 per member resolution (dataset.py:31-38), score the resident batch with every
+        member, mean over members (main.py:142-143), all-gather across ranks."""
         probs = []
+        cache = {}
         for spec, model in self.models:
-            probs.append(model.predict(self.inputs[spec.input_hw]))
+            hw = spec.input_hw
+            if hw not in cache:
+                cache[hw] = self.batch_rgb.resized(hw, hw)
+            probs.append(model.predict(cache[hw]))
         s = torch.stack(probs, 0).mean(0).reshape(-1)
         if dist is not None and self.world > 1:
             if self._gather is None:
@@ -76,7 +78,8 @@ class Workload:
 
     def config(self):
         return {"workload": self.name, "members": self.members, "batch_per_gpu": self.batch,
-                "global_batch": self.batch * self.world, "input": "200x200 RGB -> member resolution, fp16 NHWC resident",
+                "global_batch": self.batch * self.world,
+                "input": "decoded 200x200 RGB u8 resident in HBM -> bicubic resize per member resolution -> fp16 NHWC",
                 "parallelism": f"image-parallel dp{self.world}, all-gather of scores"}
 
     def roofline(self, peak_tflops: float, peak_gbs: float):
@@ -118,6 +121,8 @@ class Workload:
 def build(name: str, batch: int, rank: int = 0, world: int = 1) -> Workload:
     if name == "ensemble":
         members = zoo.ENSEMBLE
+    elif name == "ensemble8":
+        members = zoo.ENSEMBLE8
     else:
         members = [name]
     return Workload(name, members, batch, rank, world)
