@@ -52,9 +52,9 @@ __device__ __forceinline__ int swz_w(int row, int chunk) {
 template <int ACT>
 __device__ __forceinline__ float act_t(float v) {
     if constexpr (ACT == VIP_ACT_RELU) return v > 0.f ? v : 0.f;
-    else if constexpr (ACT == VIP_ACT_SILU) return v / (1.f + __expf(-v));
-    else if constexpr (ACT == VIP_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-    else if constexpr (ACT == VIP_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    else if constexpr (ACT == VIP_ACT_SILU) return v * vip_sigmoid(v);
+    else if constexpr (ACT == VIP_ACT_GELU) return 0.5f * v * (1.f + vip_erf(v * 0.70710678118654752f));
+    else if constexpr (ACT == VIP_ACT_SIGMOID) return vip_sigmoid(v);
     else return v;
 }
 
@@ -333,8 +333,14 @@ extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bi
     a.act_pre = d->act_pre; a.act_post = d->act_post;
     a.m_blocks = a.n_blocks = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (cout_g <= 64) return launch<128, 64>(a, d->groups, s);
-    return launch<128, 128>(a, d->groups, s);
+    // HBM-bound shapes (short K): a smaller M tile -> 24-48 KB LDS and half the accumulators -> 3-5 workgroups per
+    // CU in flight instead of 2, which is what hides the load -> MFMA -> store latency chain of a 1-4 k-tile block.
+    // (Tried and measured SLOWER on these shapes: a two-deep register prefetch (+40 VGPRs), an LDS-transposed
+    // "fully coalesced" epilogue, and a persistent tile loop that prefetches the next tile under the epilogue
+    // (+60 VGPRs): all three trade resident workgroups for in-workgroup overlap, and residency wins.)
+    const bool short_k = a.K <= 256;
+    if (cout_g <= 64) return short_k ? launch<64, 64>(a, d->groups, s) : launch<128, 64>(a, d->groups, s);
+    return short_k ? launch<64, 128>(a, d->groups, s) : launch<128, 128>(a, d->groups, s);
 }
 
 extern "C" int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const void* residual,
