@@ -12,13 +12,12 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int K, int TW>
+template <int K, int T, int TW>
 __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
                                                              const float* __restrict__ bias, f16* __restrict__ y,
                                                              int B, int H, int W, int C, int pt, int pl, int Ho,
                                                              int Wo, int act, int cb_chunks, int tiles_x, int tiles_y,
                                                              long n_tiles, long x_bytes) {
-    constexpr int T = 4;                 // output rows per thread
     constexpr int P = T + K - 1;         // input patch rows
     constexpr int PW = TW + K - 1;       // input patch columns (TW output columns per thread)
     extern __shared__ __attribute__((aligned(16))) float wlds[];  // [K*K][cb_chunks*8] fp32
@@ -135,20 +134,20 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
     }
 }
 
-template <int K, int TW>
+template <int K, int T, int TW>
 int launch_tile(const f16* x, const f16* w, const float* bias, f16* y, int B, int H, int W, int C, int pt, int pl,
                 int Ho, int Wo, int act, hipStream_t s) {
     const int C8 = C / 8;
     // channel chunks per block: a divisor-friendly width <= 16 chunks (128 channels) that wastes few lanes
     int cb = C8 < 16 ? C8 : 16;
     if (C8 % 12 == 0 && C8 % 16 != 0) cb = 12;                   // ConvNeXt widths 96/192/384/768
-    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + 3) / 4;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + T - 1) / T;
     const long n_tiles = (long)B * tiles_x * tiles_y;
     const int tiles_per_block = 256 / cb;
     const long gx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     const int gyc = (C8 + cb - 1) / cb;
     const size_t smem = (size_t)K * K * cb * 8 * sizeof(float);
-    hipLaunchKernelGGL((dwconv_tile_kernel<K, TW>), dim3((unsigned)gx, (unsigned)gyc), dim3(256), smem, s, x, w, bias, y, B,
+    hipLaunchKernelGGL((dwconv_tile_kernel<K, T, TW>), dim3((unsigned)gx, (unsigned)gyc), dim3(256), smem, s, x, w, bias, y, B,
                        H, W, C, pt, pl, Ho, Wo, act, cb, tiles_x, tiles_y, n_tiles, 2L * B * H * W * C);
     return vip_launch_status("vip_dwconv2d_nhwc_f16(tile)");
 }
@@ -161,11 +160,15 @@ int vip_dwconv_tiled(const void* x, const void* w, const float* bias, void* y, i
     const f16* xi = (const f16*)x;
     const f16* wi = (const f16*)w;
     f16* yo = (f16*)y;
-    const long gx = ((long)B * ((Wo + 1) / 2) * ((Ho + 3) / 4) + 15) / 16;
+    const long gx = ((long)B * ((Wo + 1) / 2) * ((Ho + 1) / 2) + 15) / 16;
     if (gx >= (1L << 31) || 2L * B * H * W * C >= 0xFFFFFFF0L) return 1;
     // tile widths chosen so that accumulators + one fp32 patch row stay well under 256 VGPRs (no scratch)
-    if (k == 3) return launch_tile<3, 4>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s);
-    if (k == 5) return launch_tile<5, 2>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s);
-    if (k == 7) return launch_tile<7, 2>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s);
+    // register tiles (rows x cols per thread) picked by measurement on the ensemble's layer shapes (tools/bench_dw.py):
+    // smaller tiles -> fewer VGPRs -> more resident waves, which beats the extra halo loads for k = 3 / 5
+#define VIP_GO(KK, TT, WW) return launch_tile<KK, TT, WW>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s)
+    if (k == 3) VIP_GO(3, 2, 2);
+    if (k == 5) VIP_GO(5, 2, 2);
+    if (k == 7) VIP_GO(7, 2, 4);
+#undef VIP_GO
     return 1;
 }
