@@ -78,6 +78,39 @@ def test_conv2d(case, report):
     check(report, f"conv2d {case}", got, ref)
 
 
+# the weights-stationary streaming kernel (1x1 stride 1, K <= 256, M >= 65536): every k-step template, ragged
+# K (not a multiple of 32), ragged N (not a multiple of 64), an M tail, N chunked over blockIdx.y, residual
+PW_CASES = [
+    # M(=B*H*W as B,H,W), Cin, Cout, act, residual
+    ((2, 181, 182), 24, 144, "silu", False),
+    ((1, 257, 256), 64, 256, "relu", True),
+    ((4, 128, 129), 96, 384, "gelu", False),
+    ((2, 200, 170), 128, 56, None, True),
+    ((1, 300, 221), 160, 960, "silu", False),
+    ((1, 256, 257), 256, 768, "gelu", True),
+    ((3, 150, 150), 40, 8, "sigmoid", False),
+]
+
+
+@pytest.mark.parametrize("case", PW_CASES, ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}")
+def test_conv2d_pointwise_stream(case, report):
+    ops = _ops()
+    (B, H, W), Cin, Cout, act, use_res = case
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = h(torch.randn(B, H, W, Cin, generator=g))
+    w = h(torch.randn(1, 1, Cin, Cout, generator=g) / math.sqrt(Cin))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    ref = R.act(R.conv2d(x, w, bias, 1, (0, 0, 0, 0), 1), act)
+    res = None
+    if use_res:
+        res = h(torch.randn(*ref.shape, generator=g))
+        ref = ref + res
+    cw = ops.make_conv_weight(w, bias)
+    got = ops.conv2d(dev(x), cw, act=act, residual=None if res is None else dev(res))
+    torch.cuda.synchronize()
+    check(report, f"conv2d pointwise-stream {case}", got, ref)
+
+
 def test_conv2d_act_post_and_channel_slices(report):
     """act applied after the residual; input/outputs addressed as channel slices of wider tensors."""
     ops = _ops()

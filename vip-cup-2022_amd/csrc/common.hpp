@@ -10,6 +10,7 @@ typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -56,11 +57,48 @@ __device__ __forceinline__ float vip_sigmoid(float v) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-v * 1.44269504088896f));
 }
 
+// ---- two-at-a-time activations: written on float2 so that hipcc emits v_pk_fma_f32 / v_pk_mul_f32 (two fp32
+// lanes per VALU slot).  GELU uses  gelu(x) = relu(x) - 0.5|x| erfc(|x|/sqrt2)  with
+// erfc(z) ~= (1 + a1 z + ... + a6 z^6)^-16  (Abramowitz-Stegun 7.1.28, |err| <= 3e-7; 1/sqrt2 folded into the
+// coefficients): ONE transcendental (rcp) instead of rcp + exp2 and no sign handling.  Max |err| 7e-7.
+__device__ __forceinline__ f32x2 vip_gelu2(f32x2 x) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    f32x2 p = ax * 5.3829750e-06f + 4.8890636e-05f;
+    p = p * ax + 3.8003575e-05f;
+    p = p * ax + 3.2776263e-03f;
+    p = p * ax + 2.1141006e-02f;
+    p = p * ax + 4.9867347e-02f;
+    p = p * ax + 1.0f;
+    f32x2 r = {__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
+    r = r * r;
+    r = r * r;
+    r = r * r;
+    r = r * r;
+    // relu(x) = 0.5x + 0.5|x|  ->  gelu = 0.5x + h (1 - r),  h = 0.5|x|   (all packed, no v_max / canonicalise)
+    const f32x2 h = ax * 0.5f;
+    const f32x2 u = h - h * r;
+    return x * 0.5f + u;
+}
+__device__ __forceinline__ f32x2 vip_sigmoid2(f32x2 v) {
+    const f32x2 t = v * -1.44269504088896f;
+    const f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const f32x2 d = e + 1.0f;
+    return (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
+template <int ACT>
+__device__ __forceinline__ f32x2 vip_act2(f32x2 v) {
+    if constexpr (ACT == VIP_ACT_RELU) return (f32x2){fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
+    else if constexpr (ACT == VIP_ACT_SILU) return v * vip_sigmoid2(v);
+    else if constexpr (ACT == VIP_ACT_GELU) return vip_gelu2(v);
+    else if constexpr (ACT == VIP_ACT_SIGMOID) return vip_sigmoid2(v);
+    else return v;
+}
+
 __device__ __forceinline__ float vip_act(float v, int act) {
     switch (act) {
         case VIP_ACT_RELU: return v > 0.f ? v : 0.f;
         case VIP_ACT_SILU: return v * vip_sigmoid(v);
-        case VIP_ACT_GELU: return 0.5f * v * (1.f + vip_erf(v * 0.70710678118654752f));
+        case VIP_ACT_GELU: return vip_gelu2((f32x2){v, v}).x;
         case VIP_ACT_SIGMOID: return vip_sigmoid(v);
         default: return v;
     }

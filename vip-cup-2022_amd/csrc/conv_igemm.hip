@@ -21,6 +21,7 @@
 // Replaces Conv2D+BN+Activation(+Add) of the reference (resnet_rs_model.py:64-84,235-280;
 // kecam common_layers.py:190-248; tfimm convnext.py:260-267,320-327) and every Dense layer.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -92,9 +93,16 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, f32x4 (&acc)[MT][4],
                 rb_res, ok ? (unsigned)((m * a.ldr + a.res_off + ch_glob + n) * 2) : OOB, 0, 0));
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[j] = act_t<ACT>(acc[mt][h * 2 + (j >> 2)][j & 3] + bv[h][j >> 2][j & 3]) + (float)r.e[j];
-                if (post_relu) v[j] = fmaxf(v[j], 0.f);
+            for (int j = 0; j < 8; j += 2) {   // pairs: packed fp32 math (v_pk_add/fma/mul_f32)
+                const f32x4 av = acc[mt][h * 2 + (j >> 2)], bb = bv[h][j >> 2];
+                const f32x2 s = (f32x2){av[j & 3], av[(j & 3) + 1]} + (f32x2){bb[j & 3], bb[(j & 3) + 1]};
+                const f32x2 t = vip_act2<ACT>(s) + (f32x2){(float)r.e[j], (float)r.e[j + 1]};
+                v[j] = t.x;
+                v[j + 1] = t.y;
+                if (post_relu) {
+                    v[j] = fmaxf(v[j], 0.f);
+                    v[j + 1] = fmaxf(v[j + 1], 0.f);
+                }
             }
             if (post_other) {
 #pragma unroll
@@ -271,6 +279,200 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
+// ---- pointwise (1x1, stride 1) / dense layers with short K: weights-stationary streaming kernel -------------
+// For K <= 256 the layer is a stream: read K halfs per pixel, write N.  The tile kernel above pays an LDS round
+// trip + barrier per k-tile for BOTH operands and re-stages the weights for every 64..128 pixels.  Here:
+//   * the block's weight slice [nb_ch x K] is staged into LDS ONCE (rows stored in MFMA-fragment order, row stride
+//     an odd number of 16-byte chunks -> conflict-free ds_read_b128) and the block then walks pixel tiles with a
+//     grid-stride loop;
+//   * the activation fragment of v_mfma_f32_16x16x32_f16 (B operand: lane = pixel, 8 consecutive k) IS a 16-byte
+//     run of an NHWC row, so it is loaded global -> VGPR directly (no LDS, no barrier in the loop) and kept in
+//     registers while the wave sweeps all output-channel sub-tiles: every activation byte is read once;
+//   * waves never synchronise after the weight staging, so one wave's epilogue (VALU + stores) overlaps the
+//     others' loads and MFMAs.
+// epilogue of the streaming kernel: the bias is already in the accumulators (it was the MFMA C operand), the
+// activation runs two values per VALU slot, and residual / post-ReLU code exists only in the variants that use it
+template <int PT, int ACT, bool RES, bool POST_RELU>
+__device__ __forceinline__ void pw_epilogue(const ConvArgs& a, f32x4 (&acc)[PT][4], int m_base, int n_first,
+                                            const __amdgpu_buffer_rsrc_t& rb_res, const __amdgpu_buffer_rsrc_t& rb_y) {
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m_base + p * 16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = n_first + h * 32;
+            const bool ok = (m < a.M) & (n < a.Cout_g);
+            U4H8 r;
+            if constexpr (RES)
+                r.u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    rb_res, ok ? (unsigned)((m * a.ldr + a.res_off + n) * 2) : OOB, 0, 0));
+            U4H8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const f32x4 av = acc[p][h * 2 + (j >> 2)];
+                f32x2 t = vip_act2<ACT>((f32x2){av[j & 3], av[(j & 3) + 1]});
+                if constexpr (RES) t = t + (f32x2){(float)r.e[j], (float)r.e[j + 1]};
+                if constexpr (POST_RELU) t = (f32x2){fmaxf(t.x, 0.f), fmaxf(t.y, 0.f)};
+                o.e[j] = (f16)t.x;
+                o.e[j + 1] = (f16)t.y;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(
+                __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o.u), rb_y,
+                ok ? (unsigned)((m * a.ldy + a.cout_off + n) * 2) : OOB, 0, 0);
+        }
+    }
+}
+
+// mode = act_pre (0..4) without residual, 5 = residual, 6 = residual + post-ReLU (both with act_pre none)
+template <int KS, int PT, bool PRE>
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(ConvArgs a, int nb_ch, int lds_stride, int n_tiles, int mode) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int n_chunk0 = blockIdx.y * nb_ch;
+    const int nch = min(nb_ch, ((a.Cout_g - n_chunk0) + 63) & ~63);   // channels computed by this block (x64)
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    float* bias_lds = reinterpret_cast<float*>(smem + nb_ch * lds_stride);
+
+    {   // stage the weight slice: LDS row j <-> channel n_chunk0 + (j & ~63) + perm(j & 63) (fragment order)
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.w, 0, (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw), 0x00020000);
+        const int cpr = KS * 4;                      // 16-byte chunks per (zero-padded) row
+        for (int i = tid; i < nch * cpr; i += 256) {
+            const int j = i / cpr, c = i - j * cpr;
+            const int t = (j >> 4) & 3, r = j & 15;
+            const int ch = n_chunk0 + (j & ~63) + (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3);
+            const bool ok = (ch < a.Cout_g) & (c * 8 < a.K);
+            const uint4 v = __builtin_bit_cast(
+                uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? (unsigned)((ch * a.ldw + c * 8) * 2) : OOB, 0, 0));
+            *reinterpret_cast<uint4*>(smem + j * lds_stride + c * 16) = v;
+        }
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.bias, 0, a.bias ? (unsigned)(a.bias_elems * 4) : 0u, 0x00020000);
+        for (int i = tid; i < nch; i += 256) {
+            const int ch = n_chunk0 + i;
+            bias_lds[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, ch < a.Cout_g ? (unsigned)(ch * 4) : OOB, 0, 0));
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + a.cin_off), 0, (unsigned)min((long)0xFFFFFFF0L, a.x_span_bytes - 2L * a.cin_off), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_res =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (unsigned)a.res_span_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (unsigned)a.y_span_bytes, 0x00020000);
+    const char* wl = smem + l15 * lds_stride + lq * 16;
+
+    auto load_x = [&](int tile, U4H8 (&xf)[KS][PT]) {
+        const int m0 = tile * (64 * PT) + wave * (16 * PT);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int m = m0 + p * 16 + l15, k = ks * 32 + lq * 8;
+                const bool ok = (m < a.M) & (k < a.K);
+                xf[ks][p].u = __builtin_bit_cast(
+                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)((m * a.ldx + k) * 2) : OOB, 0, 0));
+            }
+    };
+
+    U4H8 xf[KS][PT], xn[PRE ? KS : 1][PRE ? PT : 1];
+    int tile = blockIdx.x;
+    if (tile < n_tiles) load_x(tile, xf);
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int m0 = tile * (64 * PT) + wave * (16 * PT);
+        if constexpr (PRE) {
+            // next tile's activations: issued now, consumed after this tile's last epilogue (a tile past the end
+            // is all out-of-range offsets: no memory traffic)
+            load_x(tile + gridDim.x, xn);
+        }
+        for (int sub = 0; sub < nch; sub += 64) {
+            f32x4 acc[PT][4];
+            const char* ws = wl + sub * lds_stride;
+            f32x4 bv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                bv[nt] = *reinterpret_cast<const f32x4*>(bias_lds + sub + (nt >> 1) * 32 + lq * 8 + (nt & 1) * 4);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                U4H8 wf[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + nt * 16 * lds_stride + ks * 64);
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[ks][p].h, ks == 0 ? bv[nt] : acc[p][nt], 0, 0, 0);
+            }
+            const int m_base = m0 + l15, n_first = n_chunk0 + sub + lq * 8;
+            switch (mode) {
+                case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc, m_base, n_first, rb_res, rb_y); break;
+                case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc, m_base, n_first, rb_res, rb_y); break;
+                case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc, m_base, n_first, rb_res, rb_y); break;
+                case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc, m_base, n_first, rb_res, rb_y); break;
+                case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc, m_base, n_first, rb_res, rb_y); break;
+                case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc, m_base, n_first, rb_res, rb_y); break;
+                default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc, m_base, n_first, rb_res, rb_y); break;
+            }
+        }
+        if constexpr (PRE) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) xf[ks][p] = xn[ks][p];
+        } else {
+            if (tile + (int)gridDim.x < n_tiles) load_x(tile + gridDim.x, xf);
+        }
+    }
+}
+
+template <int KS, int PT>
+int launch_pw(const ConvArgs& a, int mode, hipStream_t s) {
+    constexpr bool PRE = KS <= 3;
+    constexpr int LDS_MAX = 72 * 1024;               // two workgroups per CU
+    int s16 = KS * 4;                                // row stride in 16-byte chunks, made odd
+    if ((s16 & 1) == 0) ++s16;
+    const int stride = s16 * 16;
+    const int cout64 = (a.Cout_g + 63) & ~63;
+    const int max_rows = (LDS_MAX / (stride + 4)) & ~63;
+    const int n_chunks = (cout64 + max_rows - 1) / max_rows;
+    const int nb_ch = (((cout64 / 64 + n_chunks - 1) / n_chunks)) * 64;
+    const int n_tiles = (a.M + 64 * PT - 1) / (64 * PT);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    int gx = (2 * n_cu + n_chunks - 1) / n_chunks;
+    if (gx > n_tiles) gx = n_tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_kernel<KS, PT, PRE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pw_gemm_kernel<KS, PT, PRE>), dim3((unsigned)gx, (unsigned)n_chunks), dim3(256),
+                       (size_t)nb_ch * (stride + 4), s, a, nb_ch, stride, n_tiles, mode);
+    return vip_launch_status("vip_conv2d_nhwc_f16(pw)");
+}
+
+template <int PT>
+int launch_pw_k(const ConvArgs& a, int mode, hipStream_t s) {
+    const int ks = (a.K + 31) >> 5;
+    switch (ks) {
+        case 1: return launch_pw<1, PT>(a, mode, s);
+        case 2: return launch_pw<2, PT>(a, mode, s);
+        case 3: return launch_pw<3, PT>(a, mode, s);
+        case 4: return launch_pw<4, PT>(a, mode, s);
+        case 5:
+        case 6: return launch_pw<6, PT>(a, mode, s);
+        default: return launch_pw<8, PT>(a, mode, s);
+    }
+}
+
 template <int BM, int BN>
 int launch(const ConvArgs& a0, int groups, hipStream_t s) {
     ConvArgs a = a0;
@@ -280,7 +482,7 @@ int launch(const ConvArgs& a0, int groups, hipStream_t s) {
     const size_t smem = (nk == 1 ? 1 : 2) * (BM + BN) * 128;  // a single k-tile needs no second stage
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * 128);
         attr_set = true;
     }
@@ -339,6 +541,16 @@ extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bi
     // "fully coalesced" epilogue, and a persistent tile loop that prefetches the next tile under the epilogue
     // (+60 VGPRs): all three trade resident workgroups for in-workgroup overlap, and residency wins.)
     const bool short_k = a.K <= 256;
+    static const int pw_mode = getenv("VIP_PW") ? atoi(getenv("VIP_PW")) : 1;
+    if (pw_mode && short_k && d->groups == 1 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 &&
+        d->pl == 0 && d->Ho == d->H && d->Wo == d->W && M >= 65536) {
+        // epilogue variants the streaming kernel carries: act_pre alone, or residual (+ post-ReLU) with no act_pre
+        int mode = -1;
+        if (!residual && d->act_post == VIP_ACT_NONE) mode = d->act_pre;
+        else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_NONE) mode = 5;
+        else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_RELU) mode = 6;
+        if (mode >= 0) return launch_pw_k<4>(a, mode, s);
+    }
     if (cout_g <= 64) return short_k ? launch<64, 64>(a, d->groups, s) : launch<128, 64>(a, d->groups, s);
     return short_k ? launch<64, 128>(a, d->groups, s) : launch<128, 128>(a, d->groups, s);
 }
