@@ -127,7 +127,8 @@ def test_conv2d_act_post_and_channel_slices(report):
     assert out[..., :48].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("M,K,N", [(256, 64, 16), (1000, 256, 768), (197 * 3, 192, 576), (5, 2048, 8), (4096, 768, 3072)])
+@pytest.mark.parametrize("M,K,N", [(256, 64, 16), (1000, 256, 768), (197 * 3, 192, 576), (5, 2048, 8), (4096, 768, 3072),
+                                   (300, 200, 136), (12544, 1248, 208), (777, 72, 40), (2500, 1536, 384)])
 def test_dense(M, K, N, report):
     ops = _ops()
     g = torch.Generator().manual_seed(M + K + N)
@@ -139,6 +140,32 @@ def test_dense(M, K, N, report):
     got = ops.dense(dev(x), ops.make_dense_weight(w, b), act="gelu", residual=dev(res))
     torch.cuda.synchronize()
     check(report, f"dense {M}x{K}x{N}", got, ref)
+
+
+# epilogue variants of the pointwise kernels (activation only / residual / residual + post-ReLU) over the general-K
+# kernel's edge cases: K tail (K % 64 != 0), odd chunk counts, N <= 64 and N not a multiple of 64/128, M tail
+@pytest.mark.parametrize("mode", ["gelu", "silu", "relu", "sigmoid", "none", "res", "res_relu"])
+@pytest.mark.parametrize("M,K,N", [(300, 200, 136), (12544, 1248, 208), (777, 72, 40), (2500, 1536, 384), (4096, 768, 3072),
+                                   (1000, 320, 64)])
+def test_dense_pointwise_modes(M, K, N, mode, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = h(torch.randn(M, K, generator=g))
+    w = h(torch.randn(K, N, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    cw = ops.make_dense_weight(w, b)
+    if mode in ("res", "res_relu"):
+        res = h(torch.randn(M, N, generator=g))
+        ref = R.dense(x, w, b) + res
+        post = "relu" if mode == "res_relu" else None
+        ref = R.act(ref, post)
+        got = ops.dense(dev(x), cw, act_post=post, residual=dev(res))
+    else:
+        act = None if mode == "none" else mode
+        ref = R.act(R.dense(x, w, b), act)
+        got = ops.dense(dev(x), cw, act=act)
+    torch.cuda.synchronize()
+    check(report, f"dense-pointwise {mode} {M}x{K}x{N}", got, ref)
 
 
 @pytest.mark.parametrize("k,s,C,H", [(3, 1, 64, 14), (3, 2, 72, 15), (5, 1, 40, 12), (5, 2, 48, 13), (7, 1, 96, 11)])

@@ -473,6 +473,168 @@ int launch_pw_k(const ConvArgs& a, int mode, hipStream_t s) {
     }
 }
 
+// ---- pointwise (1x1, stride 1) / dense layers, any K: activations direct to registers, weights through LDS ----
+// Same operand routing as the streaming kernel, for K too large to keep the weight slice resident: the block's
+// [64*NG channels] x 64-k weight chunk is double-buffered in LDS (shared by the 4 waves, one barrier per chunk);
+// each wave owns 64 pixels and loads their activation fragments global -> VGPR one chunk ahead.  Against the
+// im2col tile kernel this halves LDS traffic (no activation round trip), removes the per-k-tile im2col address
+// arithmetic from the VALU (offsets here are linear in k) and gives each wave a 64 x 128 accumulator tile.
+template <int NG>
+__global__ __launch_bounds__(256, 2) void pwk_gemm_kernel(ConvArgs a, int mode) {
+    constexpr int PT = 4, NB = 64 * NG, ROWB = 144;          // LDS row: 64 halfs + 16 B pad (odd chunk count)
+    constexpr int STAGE = NB * ROWB;
+    constexpr int W_IT = NB / 32;                            // 16-byte weight chunks staged per thread per k-chunk
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mb = bid / a.n_blocks, nb = bid - mb * a.n_blocks;
+    const int m0 = mb * (64 * PT) + wave * (16 * PT);
+    const int n0 = nb * NB;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + a.cin_off), 0, (unsigned)min((long)0xFFFFFFF0L, a.x_span_bytes - 2L * a.cin_off), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_res =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (unsigned)a.res_span_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (unsigned)a.y_span_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_bias =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)(a.bias_elems * 4) : 0u, 0x00020000);
+
+    // weight staging: thread -> (LDS row j = tid/8 + 32 i, 16-byte chunk c = tid%8); row j holds channel perm(j)
+    const int wc = tid & 7;
+    unsigned w_off[W_IT];
+    int w_lds[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int j = (tid >> 3) + 32 * i;
+        const int t = (j >> 4) & 3, r = j & 15;
+        const int ch = n0 + (j & ~63) + (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3);
+        w_off[i] = ch < a.Cout_g ? (unsigned)((ch * a.ldw + wc * 8) * 2) : OOB;
+        w_lds[i] = j * ROWB + wc * 16;
+    }
+    // activation rows of this lane: pixel m0 + 16 p + l15, k offset lq*8 (+ 32 ks + 64 chunk)
+    unsigned x_off[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m0 + p * 16 + l15;
+        x_off[p] = m < a.M ? (unsigned)((m * a.ldx + lq * 8) * 2) : 0xFFFF0000u;   // + k bytes stays out of range
+    }
+    const int nk = (a.K + 63) >> 6;
+
+    uint4 wst[W_IT];
+    auto load_w = [&](int kc) {
+        const bool ok = kc * 64 + wc * 8 < a.K;
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i)
+            wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? w_off[i] + kc * 128 : OOB, 0, 0));
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + w_lds[i]) = wst[i];
+    };
+    U4H8 xf[2][PT];
+    auto load_x = [&](int kc, int ks) {
+        // weights of the K tail are zero in LDS, but 0 * (Inf/NaN garbage of the next row) is NaN: mask the lanes
+        const bool ok = kc * 64 + ks * 32 + lq * 8 < a.K;
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+            xf[ks][p].u = __builtin_bit_cast(
+                uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + kc * 128 + ks * 64 : OOB, 0, 0));
+    };
+
+    f32x4 acc[NG][PT][4];
+    {   // bias is the C operand of the first MFMA of every accumulator
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + g * 64 + (nt >> 1) * 32 + lq * 8 + (nt & 1) * 4;
+                const f32x4 bv = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_bias, n < a.Cout_g ? (unsigned)(n * 4) : OOB, 0, 0));
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[g][p][nt] = bv;
+            }
+    }
+
+    load_w(0);
+    load_x(0, 0);
+    load_x(0, 1);
+    store_w(0);
+    __syncthreads();
+
+    auto compute = [&](int buf, int ks) {
+        const char* ws = smem + buf * STAGE + l15 * ROWB + lq * 16 + ks * 64;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            U4H8 wf[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + (g * 64 + nt * 16) * ROWB);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[ks][p].h, acc[g][p][nt], 0, 0, 0);
+        }
+    };
+
+    // One activation register set: the fragments of k-step ks are re-loaded for the NEXT chunk as soon as this
+    // chunk's MFMAs on them are issued, so each load has the other k-step's 32 MFMAs (plus the second resident
+    // wave) to land.  Everything in the loop is unconditional (a chunk past the end is all out-of-range offsets:
+    // zeros, no memory traffic): a branch around a prefetch makes hipcc fold the "loads skipped" path into its
+    // vmcnt bookkeeping and the next MFMA then waits for loads that were only just issued.
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        load_w(kc + 1);
+        __builtin_amdgcn_sched_barrier(0);   // pin the issue points: the scheduler otherwise sinks every load below
+        compute(buf, 0);                     // the MFMAs, right in front of its wait
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(kc + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(kc + 1, 1);
+        store_w(buf ^ 1);
+        __syncthreads();
+    }
+
+    // opaque to the optimiser: otherwise the epilogue's address arithmetic is hoisted above the k-loop and its
+    // ~20 registers stay live through it (the loop is at the 256-VGPR limit of two waves per SIMD)
+    int m_base = m0 + l15, n_lane = n0 + lq * 8;
+    asm volatile("" : "+v"(m_base), "+v"(n_lane));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int n_first = n_lane + g * 64;
+        switch (mode) {
+            case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+        }
+    }
+}
+
+template <int NG>
+int launch_pwk(const ConvArgs& a0, int mode, hipStream_t s) {
+    ConvArgs a = a0;
+    a.m_blocks = (a.M + 255) / 256;
+    a.n_blocks = (a.Cout_g + 64 * NG - 1) / (64 * NG);
+    hipLaunchKernelGGL((pwk_gemm_kernel<NG>), dim3((unsigned)(a.m_blocks * a.n_blocks)), dim3(256), 0, s, a, mode);
+    return vip_launch_status("vip_conv2d_nhwc_f16(pwk)");
+}
+
 template <int BM, int BN>
 int launch(const ConvArgs& a0, int groups, hipStream_t s) {
     ConvArgs a = a0;
@@ -541,15 +703,18 @@ extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bi
     // "fully coalesced" epilogue, and a persistent tile loop that prefetches the next tile under the epilogue
     // (+60 VGPRs): all three trade resident workgroups for in-workgroup overlap, and residency wins.)
     const bool short_k = a.K <= 256;
-    static const int pw_mode = getenv("VIP_PW") ? atoi(getenv("VIP_PW")) : 1;
-    if (pw_mode && short_k && d->groups == 1 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 &&
-        d->pl == 0 && d->Ho == d->H && d->Wo == d->W && M >= 65536) {
-        // epilogue variants the streaming kernel carries: act_pre alone, or residual (+ post-ReLU) with no act_pre
+    static const int pw_mode = getenv("VIP_PW") ? atoi(getenv("VIP_PW")) : 3;
+    if (pw_mode && d->groups == 1 && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->pt == 0 && d->pl == 0 &&
+        d->Ho == d->H && d->Wo == d->W) {
+        // epilogue variants the pointwise kernels carry: act_pre alone, or residual (+ post-ReLU) with no act_pre
         int mode = -1;
         if (!residual && d->act_post == VIP_ACT_NONE) mode = d->act_pre;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_NONE) mode = 5;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_RELU) mode = 6;
-        if (mode >= 0) return launch_pw_k<4>(a, mode, s);
+        if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536) return launch_pw_k<4>(a, mode, s);
+        if (mode >= 0 && (pw_mode & 2) && a.x_span_bytes < 0xFFFF0000L - 2L * a.K)
+            // (a 64 x 256 wave tile at one wave per SIMD - NG = 4 - measured 15-40 % slower than NG = 2 at two)
+            return cout_g <= 64 ? launch_pwk<1>(a, mode, s) : launch_pwk<2>(a, mode, s);
     }
     if (cout_g <= 64) return short_k ? launch<64, 64>(a, d->groups, s) : launch<128, 64>(a, d->groups, s);
     return short_k ? launch<64, 128>(a, d->groups, s) : launch<128, 128>(a, d->groups, s);
