@@ -1,4 +1,4 @@
-// Depthwise convolution, stride 1, register-tiled: each thread owns a 4x4 patch of output pixels for 8
+// Depthwise convolution, stride 1, register-tiled: each thread owns a T x TW patch of output pixels for 8
 // channels and walks the (4+K-1) input rows ONCE (one 16-byte load and one fp16->fp32 conversion per input
 // chunk, 6.25 loads per output chunk for K=7 instead of 17.5), with the K*K*C filter pre-converted to fp32 in
 // LDS (every lane of a channel chunk reads the same address: broadcast, conflict-free).
@@ -10,9 +10,35 @@
 
 namespace {
 
+static int VIP_DW_BLOCKS_PER_CU = 8;
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int K, int T, int TW>
+
+template <int T, int TW, int ACT>
+__device__ __forceinline__ void dw_store(f32x2 (&acc)[T][TW][4], const float (&bv)[8], f16* __restrict__ y, int b, int oy0,
+                                         int ox0, int Ho, int Wo, int C, int c0) {
+#pragma unroll
+    for (int oy = 0; oy < T; ++oy) {
+        const int gy = oy0 + oy;
+        if (gy >= Ho) break;
+#pragma unroll
+        for (int ox = 0; ox < TW; ++ox) {
+            const int gx = ox0 + ox;
+            if (gx >= Wo) break;
+            U4H8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 v = vip_act2<ACT>(acc[oy][ox][e] + (f32x2){bv[2 * e], bv[2 * e + 1]});
+                o.e[2 * e] = (f16)v.x;
+                o.e[2 * e + 1] = (f16)v.y;
+            }
+            *reinterpret_cast<uint4*>(y + (((long)b * Ho + gy) * Wo + gx) * C + c0) = o.u;
+        }
+    }
+}
+
+template <int K, int T, int TW, bool WHOLE>
 __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
                                                              const float* __restrict__ bias, f16* __restrict__ y,
                                                              int B, int H, int W, int C, int pt, int pl, int Ho,
@@ -35,14 +61,19 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
     const int tiles_per_block = 256 / cb_chunks;
     const int lc = threadIdx.x % cb_chunks;                 // chunk inside the block (fastest: coalesced rows)
     const int lt = threadIdx.x / cb_chunks;
-    const long tile = (long)blockIdx.x * tiles_per_block + lt;
-    if (lt >= tiles_per_block || tile >= n_tiles || lc >= nch) return;
+    if (lt >= tiles_per_block || lc >= nch) return;
+    const int c0 = (c8_0 + lc) * 8;
+    const float* wl = wlds + lc * 8;
+    // buffer descriptor over the whole input: out-of-image taps use an out-of-range offset and read as zero in
+    // hardware (a `cond ? load : 0` in source makes hipcc predicate + serialise every load, see conv_igemm.hip)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)x_bytes, 0x00020000);
+
+    // the block walks tile groups with a grid stride: the filter staging above is paid once per block
+    for (long tile = (long)blockIdx.x * tiles_per_block + lt; tile < n_tiles; tile += (long)gridDim.x * tiles_per_block) {
     const int tx = (int)(tile % tiles_x);
     const int ty = (int)((tile / tiles_x) % tiles_y);
     const int b = (int)(tile / ((long)tiles_x * tiles_y));
     const int oy0 = ty * T, ox0 = tx * TW;
-    const int c0 = (c8_0 + lc) * 8;
-    const float* wl = wlds + lc * 8;
 
     f32x2 acc[T][TW][4];
 #pragma unroll
@@ -52,9 +83,6 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[i][j][q] = (f32x2){0.f, 0.f};
 
-    // buffer descriptor over the whole input: out-of-image taps use an out-of-range offset and read as zero in
-    // hardware (a `cond ? load : 0` in source makes hipcc predicate + serialise every load, see conv_igemm.hip)
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)x_bytes, 0x00020000);
     const unsigned xoff0 = (unsigned)((((long)b * H * W) * C + c0) * 2);
     auto load_row = [&](int iy, uint4 (&raw)[PW]) {
         const int gy = oy0 - pt + iy;
@@ -67,19 +95,13 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
             raw[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
     };
-    uint4 raw[PW];
-    load_row(0, raw);
-    // NOT unrolled (unrolling makes hipcc hoist every load and spill); the NEXT row's loads are issued before the
-    // current row is converted and multiplied, so their latency hides under ~400 VALU instructions
-#pragma unroll 1
-    for (int iy = 0; iy < P; ++iy) {
-        uint4 nxt[PW];
-        load_row(iy + 1 < P ? iy + 1 : iy, nxt);
+    // multiply-accumulate one converted input row into the output rows it feeds
+    auto mac_row = [&](int iy, const uint4 (&rawrow)[PW]) {
         f32x2 xr[PW][4];
 #pragma unroll
         for (int q = 0; q < PW; ++q) {
             U4H8 v;
-            v.u = raw[q];
+            v.u = rawrow[q];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 xr[q][e][0] = (float)v.e[2 * e];
@@ -108,33 +130,48 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
                 w1 = n1;
             }
         }
+    };
+    if constexpr (WHOLE) {
+        // small filters: the whole (T+K-1) x (TW+K-1) patch is requested up front - a row's ~100 VALU instructions
+        // cannot cover a memory round trip, P x PW loads in flight per lane can
+        uint4 raw[P][PW];
 #pragma unroll
-        for (int q = 0; q < PW; ++q) raw[q] = nxt[q];
-    }
-
-    float bv[8];
+        for (int iy = 0; iy < P; ++iy) load_row(iy, raw[iy]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[c0 + j] : 0.f;
+        for (int iy = 0; iy < P; ++iy) mac_row(iy, raw[iy]);
+    } else {
+        uint4 raw[PW];
+        load_row(0, raw);
+        // NOT unrolled (unrolling makes hipcc hoist every load and spill); the NEXT row's loads are issued before the
+        // current row is converted and multiplied, so their latency hides under ~400 VALU instructions
+#pragma unroll 1
+        for (int iy = 0; iy < P; ++iy) {
+            uint4 nxt[PW];
+            load_row(iy + 1 < P ? iy + 1 : iy, nxt);
+            mac_row(iy, raw);
 #pragma unroll
-    for (int oy = 0; oy < T; ++oy) {
-        const int gy = oy0 + oy;
-        if (gy >= Ho) break;
-#pragma unroll
-        for (int ox = 0; ox < TW; ++ox) {
-            const int gx = ox0 + ox;
-            if (gx >= Wo) break;
-            U4H8 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o.e[2 * e] = (f16)vip_act(acc[oy][ox][e][0] + bv[2 * e], act);
-                o.e[2 * e + 1] = (f16)vip_act(acc[oy][ox][e][1] + bv[2 * e + 1], act);
-            }
-            *reinterpret_cast<uint4*>(y + (((long)b * Ho + gy) * Wo + gx) * C + c0) = o.u;
+            for (int q = 0; q < PW; ++q) raw[q] = nxt[q];
         }
     }
+
+    float bv[8];     // loaded per tile (L1-resident): keeping it across the tile loop costs 8 VGPRs of a full budget
+    {
+        const float4 b0 = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b1 = bias ? *reinterpret_cast<const float4*>(bias + c0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+        bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+    switch (act) {   // one straight-line, packed-math epilogue per activation
+        case VIP_ACT_RELU: dw_store<T, TW, VIP_ACT_RELU>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
+        case VIP_ACT_SILU: dw_store<T, TW, VIP_ACT_SILU>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
+        case VIP_ACT_GELU: dw_store<T, TW, VIP_ACT_GELU>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
+        case VIP_ACT_SIGMOID: dw_store<T, TW, VIP_ACT_SIGMOID>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
+        default: dw_store<T, TW, VIP_ACT_NONE>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
+    }
+    }   // tile loop
 }
 
-template <int K, int T, int TW>
+template <int K, int T, int TW, bool WHOLE>
 int launch_tile(const f16* x, const f16* w, const float* bias, f16* y, int B, int H, int W, int C, int pt, int pl,
                 int Ho, int Wo, int act, hipStream_t s) {
     const int C8 = C / 8;
@@ -144,10 +181,12 @@ int launch_tile(const f16* x, const f16* w, const float* bias, f16* y, int B, in
     const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + T - 1) / T;
     const long n_tiles = (long)B * tiles_x * tiles_y;
     const int tiles_per_block = 256 / cb;
-    const long gx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
     const int gyc = (C8 + cb - 1) / cb;
+    long gx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    const long gx_cap = (256L * VIP_DW_BLOCKS_PER_CU + gyc - 1) / gyc;     // ~resident blocks of the whole chip
+    if (gx > gx_cap) gx = gx_cap;
     const size_t smem = (size_t)K * K * cb * 8 * sizeof(float);
-    hipLaunchKernelGGL((dwconv_tile_kernel<K, T, TW>), dim3((unsigned)gx, (unsigned)gyc), dim3(256), smem, s, x, w, bias, y, B,
+    hipLaunchKernelGGL((dwconv_tile_kernel<K, T, TW, WHOLE>), dim3((unsigned)gx, (unsigned)gyc), dim3(256), smem, s, x, w, bias, y, B,
                        H, W, C, pt, pl, Ho, Wo, act, cb, tiles_x, tiles_y, n_tiles, 2L * B * H * W * C);
     return vip_launch_status("vip_dwconv2d_nhwc_f16(tile)");
 }
@@ -165,10 +204,12 @@ int vip_dwconv_tiled(const void* x, const void* w, const float* bias, void* y, i
     // tile widths chosen so that accumulators + one fp32 patch row stay well under 256 VGPRs (no scratch)
     // register tiles (rows x cols per thread) picked by measurement on the ensemble's layer shapes (tools/bench_dw.py):
     // smaller tiles -> fewer VGPRs -> more resident waves, which beats the extra halo loads for k = 3 / 5
-#define VIP_GO(KK, TT, WW) return launch_tile<KK, TT, WW>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s)
-    if (k == 3) VIP_GO(3, 2, 2);
-    if (k == 5) VIP_GO(5, 2, 2);
-    if (k == 7) VIP_GO(7, 2, 4);
+#define VIP_GO(KK, TT, WW, WH) return launch_tile<KK, TT, WW, WH>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s)
+    // measured on the ensemble's layer shapes (tools/bench_dw.py): 3x3 wants the whole 4x6 patch in flight (+15-25 %
+    // over row-at-a-time); 5x5 / 7x7 whole-patch variants spill, and their rows carry enough FMAs to cover a load
+    if (k == 3) VIP_GO(3, 2, 4, true);
+    if (k == 5) VIP_GO(5, 2, 2, false);
+    if (k == 7) VIP_GO(7, 2, 4, false);
 #undef VIP_GO
     return 1;
 }
