@@ -7,7 +7,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from . import ops, pipeline
+from . import ensemble, ops, pipeline
 from . import zoo
 
 DEFAULT = "ensemble"
@@ -56,17 +56,18 @@ class Workload:
         self.batch_rgb = pipeline.DecodedBatch(rgb, sizes, [(200, 200)] * batch)
         self.scores = None
         self._gather = None
+        self.member_streams = ensemble.MemberStreams(ensemble.default_streams())
+        self._serial = ensemble.MemberStreams(1)
 
-    def step(self, dist=None):
+    def step(self, dist=None, serial: bool = False):
         """cast+resize+/255 per member resolution (dataset.py:31-38), score the resident batch with every
         member, mean over members (main.py:142-143), all-gather across ranks."""
-        probs = []
         cache = {}
-        for spec, model in self.models:
+        for spec, _ in self.models:
             hw = spec.input_hw
             if hw not in cache:
                 cache[hw] = self.batch_rgb.resized(hw, hw)
-            probs.append(model.predict(cache[hw]))
+        probs = (self._serial if serial else self.member_streams).predict_all(self.models, cache)
         s = torch.stack(probs, 0).mean(0).reshape(-1)
         if dist is not None and self.world > 1:
             if self._gather is None:
@@ -80,14 +81,15 @@ class Workload:
         return {"workload": self.name, "members": self.members, "batch_per_gpu": self.batch,
                 "global_batch": self.batch * self.world,
                 "input": "decoded 200x200 RGB u8 resident in HBM -> bicubic resize per member resolution -> fp16 NHWC",
-                "parallelism": f"image-parallel dp{self.world}, all-gather of scores"}
+                "parallelism": f"image-parallel dp{self.world}, all-gather of scores",
+                "member_streams": self.member_streams.n}
 
     def roofline(self, peak_tflops: float, peak_gbs: float):
         """One instrumented step: per-kernel-family time from HIP events around each launch."""
         prof = KernelProfile()
         ops.set_profiler(prof)
         try:
-            self.step(None)
+            self.step(None, serial=True)      # one stream: per-launch HIP events see only their own kernel
         finally:
             ops.set_profiler(None)
         summ = prof.summary()
