@@ -10,7 +10,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 TOP = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 wl = workloads.build(name, B)
 for _ in range(2):
-    wl.step()
+    wl.step(serial=True)
 torch.cuda.synchronize()
 rec = []
 NAMES = ["conv2d", "dense", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "scale_add_act",
@@ -43,7 +43,7 @@ def wrap(nm, fn):
 
 for nm in NAMES:
     setattr(ops, nm, wrap(nm, getattr(ops, nm)))
-wl.step()
+wl.step(serial=True)
 torch.cuda.synchronize()
 per_op = collections.OrderedDict()
 agg = collections.OrderedDict()

@@ -9,7 +9,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "ensemble"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 wl = workloads.build(name, B)
 for _ in range(2):
-    wl.step()
+    wl.step(serial=True)
 torch.cuda.synchronize()
 
 rec = []
@@ -35,7 +35,7 @@ def dense(x, cw, act=None, act_post=None, residual=None):
     return y
 
 ops.conv2d, ops.dense = conv2d, dense
-wl.step()
+wl.step(serial=True)
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
 for k, fl, by, e0, e1 in rec:

@@ -37,7 +37,7 @@ struct WinArgs {
     int B, Hp, Wp, C, heads, nq;
     int nWy, nWx;
     int items;
-    float scale_log2e;
+    float scale_log2e, inv_scale;
 };
 
 template <int WS, int P, int LOG2P, int WPI>
@@ -47,11 +47,14 @@ struct WinCfg {
     static constexpr int NQT = (WS * WS + 15) / 16;     // 16-query tiles over the DENSE token order (4 / 13)
     static constexpr int IPW = 4 / WPI;
     static constexpr int ROWB = 64;
-    static constexpr int KCMAX = 32 * NKT;
+    // bias-table row stride (floats).  ws 14: 48, not 32 - with a 32-float stride the two token rows a query tile
+    // spans land on the same LDS banks (2-way conflicts on 28 % of the table reads); 48 shifts them by 16 banks.
+    static constexpr int TW = (P == 16) ? 48 : 2 * P;
+    static constexpr int KSTEP = TW * 16 / P;           // table-offset step of one 16-key tile
+    static constexpr int KCMAX = KSTEP * NKT;
     static constexpr int NEGSZ = KCMAX + 4;
     static constexpr int TOFF = NEGSZ + KCMAX;
     static constexpr int TROWS = 2 * WS - 1;
-    static constexpr int TW = 2 * P;
     static constexpr int TB_FLOATS = TOFF + TROWS * TW;
     static constexpr int K_OFF = 0;
     static constexpr int V_OFF = RP * ROWB;
@@ -77,7 +80,16 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
     const int wave = tid >> 6;
     const int slot = wave / WPI;
     const int lt = tid - slot * WPI * 64;
-    int item = blockIdx.x * Cfg::IPW + slot;
+    // XCD-aware block order: consecutive logical blocks (the heads of one window: neighbouring 64-byte slices of the
+    // same 128-byte lines) run on the same XCD and share its L2, instead of each XCD fetching the line for itself
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int item = bid * Cfg::IPW + slot;
     const bool item_ok = item < a.items;
     if (!item_ok) item = a.items - 1;
     const int head = item % a.heads;
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
             const bool in_tab = (i >= Cfg::TOFF) & (i < Cfg::TB_FLOATS) & (rx < Cfg::TROWS);
             const int gi = in_tab ? (ry * Cfg::TROWS + rx) * a.heads + head : 0;
             const float t = a.table[gi];
-            tv[it] = in_tab ? t * 1.44269504088896f : (i < Cfg::TOFF ? -1.0e30f : 0.f);
+            tv[it] = in_tab ? t * a.inv_scale : (i < Cfg::TOFF ? -1.0e30f : 0.f);
         }
 #pragma unroll
         for (int it = 0; it < TIT; ++it) {
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
 
     const float sc = a.scale_log2e;
     // lane-dependent part of the key term 2k' - kx  (k' = 16t + 4g + r)
-    const int lane_term = (P == 16) ? 4 * g : 8 * g - 4 * (g & 1);
+    const int lane_term = (P == 16) ? 4 * g : (g >> 1) * Cfg::TW + 4 * (g & 1);
     // LDS byte offsets of this lane's fragment reads
     const int tr_q = l15 >> 2, tr_p = l15 & 3;
 
@@ -177,7 +189,13 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
         if (qt >= NQT) break;  // wave-uniform
         const int qn = qt * 16 + l15;
 
-        // S^T tiles: rows = keys 16t + 4g + r, column = this lane's query
+        // S^T tiles: rows = keys 16t + 4g + r, column = this lane's query.  The relative-position bias (stored as
+        // table/scale, padded key slots redirected to the -1e30 block) is added with one packed add per pair (as the MFMA
+        // C operand it cost a v_mov per value to assemble), so the softmax needs one packed FMA + one exp2 per score:
+        //   p = exp2(scale*log2e * s' - scale*log2e * max s')
+        const int qy = qn / WS, qx = qn - qy * WS;
+        const int qyc = qy < WS ? qy : WS - 1, qxc = qx;
+        const float* tbase = tb + (Cfg::TOFF + qyc * Cfg::TW + qxc + (WS - 1) * (Cfg::TW + 1) - lane_term - Cfg::KCMAX);
         f32x4 acc[NKT];
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -186,47 +204,55 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
             kf.u = *reinterpret_cast<const uint4*>(k_lds + row * Cfg::ROWB + k_slot(row, g) * 16);
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf.h, qf[i].h, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
-
-        // scale + relative-position bias (+ key padding mask), running max
-        const int qy = qn / WS, qx = qn - qy * WS;
-        const int qyc = qy < WS ? qy : WS - 1, qxc = qx;
-        const float* tbase = tb + (Cfg::TOFF + qyc * Cfg::TW + qxc + (WS - 1) * (Cfg::TW + 1) - lane_term - Cfg::KCMAX);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                f32x2 bv;
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    // which lane groups g hold a padded key slot in register (t, r+rr)?  (compile-time 4-bit mask)
+                    int mask = 0;
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const int kp = 16 * t + 4 * gg + r + rr;
+                        if (((kp & (P - 1)) >= WS) || ((kp >> LOG2P) >= WS)) mask |= 1 << gg;
+                    }
+                    if (mask == 15) {
+                        bv[rr] = -1.0e30f;
+                    } else {
+                        const int imm = Cfg::KCMAX - (Cfg::KSTEP * t + r + rr);
+                        const float* bp = (mask == 0) ? tbase : (((mask >> g) & 1) ? tb : tbase);
+                        bv[rr] = bp[imm];
+                    }
+                }
+                const f32x2 sv = (f32x2){acc[t][r], acc[t][r + 1]} + bv;   // v_pk_add_f32
+                acc[t][r] = sv.x;
+                acc[t][r + 1] = sv.y;
+            }
+        }
         float m = -1.0e30f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // which lane groups g hold a padded key slot in register (t, r)?  (compile-time 4-bit mask)
-                int mask = 0;
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    const int kp = 16 * t + 4 * gg + r;
-                    if (((kp & (P - 1)) >= WS) || ((kp >> LOG2P) >= WS)) mask |= 1 << gg;
-                }
-                float s;
-                if (mask == 15) {
-                    s = -1.0e30f;
-                } else {
-                    const int imm = Cfg::KCMAX - (32 * t + r);
-                    const float* bp = (mask == 0) ? tbase : (((mask >> g) & 1) ? tb : tbase);
-                    s = acc[t][r] * sc + bp[imm];
-                }
-                acc[t][r] = s;
-                m = fmaxf(m, s);
-            }
+            m = fmaxf(fmaxf(m, acc[t][0]), acc[t][1]);   // v_max3_f32
+            m = fmaxf(fmaxf(m, acc[t][2]), acc[t][3]);
         }
         m = fmaxf(m, __shfl_xor(m, 16, 64));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
-        float lsum = 0.f;
+        const f32x2 nm = {-m * sc, -m * sc};
+        f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(acc[t][r] - m);
-                acc[t][r] = p;
-                lsum += p;
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 e = (f32x2){acc[t][r], acc[t][r + 1]} * sc + nm;      // v_pk_fma_f32
+                const f32x2 p = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+                acc[t][r] = p.x;
+                acc[t][r + 1] = p.y;
+                ls2 += p;                                                         // v_pk_add_f32
             }
         }
+        float lsum = ls2.x + ls2.y;
         lsum += __shfl_xor(lsum, 16, 64);
         lsum += __shfl_xor(lsum, 32, 64);
 
@@ -297,8 +323,8 @@ extern "C" int vip_window_attn_fwd_f16(const void* qkv, const void* q_global, co
     VIP_REQUIRE(qkv && bias_table && out, VIP_ERR_BAD_ARG, "vip_window_attn_fwd_f16: null pointer");
     VIP_REQUIRE(nq == 3 || (nq == 2 && q_global), VIP_ERR_BAD_ARG,
                 "vip_window_attn_fwd_f16: nq must be 3, or 2 with a q_global tensor");
-    VIP_REQUIRE(B > 0 && Hp > 0 && Wp > 0 && C > 0 && heads > 0, VIP_ERR_BAD_ARG,
-                "vip_window_attn_fwd_f16: non-positive dimension");
+    VIP_REQUIRE(B > 0 && Hp > 0 && Wp > 0 && C > 0 && heads > 0 && scale > 0.f, VIP_ERR_BAD_ARG,
+                "vip_window_attn_fwd_f16: non-positive dimension or scale");
     VIP_REQUIRE(C == heads * 32, VIP_ERR_UNSUPPORTED, "vip_window_attn_fwd_f16: head_dim = C/heads must be 32 (C=%d heads=%d)", C, heads);
     VIP_REQUIRE(ws == 7 || ws == 14, VIP_ERR_UNSUPPORTED, "vip_window_attn_fwd_f16: window size %d (only 7, 14)", ws);
     VIP_REQUIRE(Hp % ws == 0 && Wp % ws == 0, VIP_ERR_BAD_ARG,
@@ -311,6 +337,7 @@ extern "C" int vip_window_attn_fwd_f16(const void* qkv, const void* q_global, co
     VIP_REQUIRE(items < (1L << 30), VIP_ERR_UNSUPPORTED, "vip_window_attn_fwd_f16: too many windows");
     a.items = (int)items;
     a.scale_log2e = scale * 1.44269504088896f;
+    a.inv_scale = 1.f / scale;
     if (ws == 7) return launch_win<7, 8, 3, 1>(a, (hipStream_t)stream);
     return launch_win<14, 16, 4, 4>(a, (hipStream_t)stream);
 }
