@@ -68,8 +68,23 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
     // hardware (a `cond ? load : 0` in source makes hipcc predicate + serialise every load, see conv_igemm.hip)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)x_bytes, 0x00020000);
 
-    // the block walks tile groups with a grid stride: the filter staging above is paid once per block
-    for (long tile = (long)blockIdx.x * tiles_per_block + lt; tile < n_tiles; tile += (long)gridDim.x * tiles_per_block) {
+    // The block walks tile groups with a stride (the filter staging above is paid once per block).  XCD-aware: blocks
+    // b, b+8, ... share an XCD and its L2, so each XCD gets one CONTIGUOUS band of tile groups - vertically adjacent
+    // tiles re-read K-1 of their T+K-1 input rows, and with a plain grid stride those neighbours sit on other XCDs and
+    // every XCD pulls the halo rows over the fabric again (PMC: 2.7x the algorithmic read bytes).
+    const long n_groups = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    long g_lo = 0, g_hi = n_groups, g_step = gridDim.x, g_first = blockIdx.x;
+    if (gridDim.x >= 8) {
+        const int xcd = blockIdx.x & 7;
+        const long chunk = (n_groups + 7) / 8;
+        g_lo = xcd * chunk;
+        g_hi = min(n_groups, g_lo + chunk);
+        g_step = (gridDim.x + 7 - xcd) >> 3;           // blocks that share this XCD id
+        g_first = g_lo + (blockIdx.x >> 3);
+    }
+    for (long grp = g_first; grp < g_hi; grp += g_step) {
+    const long tile = grp * tiles_per_block + lt;
+    if (tile >= n_tiles) break;
     const int tx = (int)(tile % tiles_x);
     const int ty = (int)((tile / tiles_x) % tiles_y);
     const int b = (int)(tile / ((long)tiles_x * tiles_y));

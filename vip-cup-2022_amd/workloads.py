@@ -102,13 +102,13 @@ class Workload:
         tf = d["flops"] / sec / 1e12
         gbs = d["bytes"] / sec / 1e9
         intensity = d["flops"] / max(d["bytes"], 1.0)
+        label = {"conv_igemm_kernel": "conv/GEMM family: conv_igemm_kernel + pw_gemm_kernel + pwk_gemm_kernel"}.get(fam, fam)
+        common = {"kernel": label, "traffic": _pmc_traffic(fam), "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/)",
+                  "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "launches": d["launches"],
+                  "avg_launch_ms": d["ms"] / d["launches"]}
         if intensity * peak_gbs * 1e9 >= peak_tflops * 1e12:
-            return {"kernel": fam, "bound": "mfma", "achieved": tf, "peak": peak_tflops, "unit": "TFLOP/s",
-                    "frac": tf / peak_tflops, "traffic": None, "launches": d["launches"],
-                    "avg_launch_ms": d["ms"] / d["launches"]}
-        return {"kernel": fam, "bound": "hbm", "achieved": gbs, "peak": peak_gbs, "unit": "GB/s",
-                "frac": gbs / peak_gbs, "traffic": None, "launches": d["launches"],
-                "avg_launch_ms": d["ms"] / d["launches"]}
+            return {"bound": "mfma", "achieved": tf, "peak": peak_tflops, "unit": "TFLOP/s", "frac": tf / peak_tflops, **common}
+        return {"bound": "hbm", "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs, **common}
 
     def extra(self):
         summ = getattr(self, "_summ", None)
@@ -118,6 +118,19 @@ class Workload:
                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
                     "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def _pmc_traffic(fam: str):
+    """HBM bytes per launch of a kernel family from the committed PMC summary of this bench command
+    (tools/pmc_traffic.py over `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes), or None."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_hbm_traffic_pmc.json")
+    key = {"conv_igemm_kernel": "conv_gemm", "window_attn_kernel": "window_attn"}.get(fam)
+    try:
+        return json.load(open(path))[key]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def build(name: str, batch: int, rank: int = 0, world: int = 1) -> Workload:
