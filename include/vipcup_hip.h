@@ -86,6 +86,22 @@ int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const
                           int act_pre, int act_post, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused two-layer MLP:  y[M,C] = W2 . act(W1 . x + b1) + b2 (+ residual), hidden tensor never written to memory.
+ * Replaces Dense -> GELU -> Dense (-> layer-scale, folded by the caller) -> Add of
+ *   tfimm/architectures/convnext.py:200-229, gcvit/layers/feature.py:20-22 (Mlp),
+ *   tfimm/layers/transformers.py:192-205 (MLP)
+ * for narrow token widths whose two weight matrices fit in LDS together.
+ *   x [M][ldx] f16 ; w1 [hidden][ldw1] f16 (rows = hidden channels, C contiguous) ; b1 [hidden] f32 or NULL ;
+ *   w2 [C][ldw2] f16 (rows = output channels, hidden contiguous) ; b2 [C] f32 or NULL ; residual [M][ldr] or NULL.
+ * vip_mlp_fused_supported() says whether a shape is handled (C in {64, 96}, act = GELU, hidden % 32 == 0, both
+ * matrices <= 160 KB of LDS, M >= 8192); otherwise use two vip_gemm_bias_act_f16 calls.
+ * ------------------------------------------------------------------------------------------ */
+int vip_mlp_fused_supported(int M, int C, int hidden, int act);
+int vip_mlp_fused_f16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                      const void* residual, void* y, int M, int C, int hidden, int ldx, int ldw1, int ldw2,
+                      int ldy, int ldr, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Depthwise Conv2D k x k (+bias)(+act).  Replaces tf.keras.layers.DepthwiseConv2D:
  *   gcvit/layers/feature.py:93,133 ; tfimm/architectures/convnext.py:192-198 ;
  *   kecam efficientnet_v2.py:85 (common_layers.py:251-265).

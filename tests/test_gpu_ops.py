@@ -168,6 +168,31 @@ def test_dense_pointwise_modes(M, K, N, mode, report):
     check(report, f"dense-pointwise {mode} {M}x{K}x{N}", got, ref)
 
 
+# fused MLP (hidden tensor in registers): both supported widths, M tails, with/without residual, vs two fp32 denses
+@pytest.mark.parametrize("M,C,hid,use_res", [(8192, 96, 384, True), (20011, 96, 384, False), (9000, 64, 256, True),
+                                             (8192 + 513, 64, 192, True)])
+def test_mlp_fused(M, C, hid, use_res, report):
+    ops = _ops()
+    from vipcup_amd import _abi
+    assert _abi.lib().vip_mlp_fused_supported(M, C, hid, 3)
+    g = torch.Generator().manual_seed(M + C + hid)
+    x = h(torch.randn(M, C, generator=g))
+    w1 = h(torch.randn(C, hid, generator=g) / math.sqrt(C))
+    b1 = torch.randn(hid, generator=g) * 0.1
+    w2 = h(torch.randn(hid, C, generator=g) / math.sqrt(hid))
+    b2 = torch.randn(C, generator=g) * 0.1
+    res = h(torch.randn(M, C, generator=g)) if use_res else None
+    ref = R.dense(R.act(R.dense(x, w1, b1), "gelu"), w2, b2)
+    if use_res:
+        ref = ref + res
+    got = ops.mlp(dev(x), ops.make_dense_weight(w1, b1), ops.make_dense_weight(w2, b2), act="gelu",
+                  residual=None if res is None else dev(res))
+    torch.cuda.synchronize()
+    # the hidden activations are rounded to fp16 before the second GEMM on both paths of the product; against the
+    # fp32 oracle that is one extra fp16 rounding inside a K = hid dot product
+    check(report, f"mlp_fused M{M} C{C} hid{hid} res{use_res}", got, ref, tol=3e-3)
+
+
 @pytest.mark.parametrize("k,s,C,H", [(3, 1, 64, 14), (3, 2, 72, 15), (5, 1, 40, 12), (5, 2, 48, 13), (7, 1, 96, 11)])
 def test_dwconv(k, s, C, H, report):
     ops = _ops()

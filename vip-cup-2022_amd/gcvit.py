@@ -127,8 +127,7 @@ class _Block:
         att = ops.window_attention(qkv, q_global if self.global_query else None, self.table, self.heads, self.ws,
                                    hd ** -0.5)
         x = ops.dense(att, self.proj, residual=x)            # x + attn   (gamma1 = 1, block.py:54-56,79)
-        h = ops.dense(self.n2(x), self.fc1, act="gelu")
-        return ops.dense(h, self.fc2, residual=x)            # x + mlp    (:80)
+        return ops.mlp(self.n2(x), self.fc1, self.fc2, act="gelu", residual=x)   # x + mlp    (:80)
 
 
 class GCViT:

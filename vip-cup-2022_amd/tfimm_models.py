@@ -114,8 +114,7 @@ class ViT:
             qkv = ops.dense(blk["n1"](t), blk["qkv"])
             att = ops.mhsa(qkv, cfg.nb_heads, scale)
             t = ops.dense(att, blk["proj"], residual=t)
-            h = ops.dense(blk["n2"](t), blk["fc1"], act="gelu")
-            t = ops.dense(h, blk["fc2"], residual=t)
+            t = ops.mlp(blk["n2"](t), blk["fc1"], blk["fc2"], act="gelu", residual=t)
             if collect is not None:
                 collect.append(t)
         return self.norm(t)
@@ -211,8 +210,7 @@ class ConvNeXt:
                 y = ops.conv2d(ln(y), cw, stride=2)                               # 2x2/2 VALID (convnext.py:260-267)
             for blk in st["blocks"]:                                              # ConvNeXtBlock.call (:220-229)
                 h = ops.dwconv2d(y, blk["dw"], blk["dwb"], 7, 1, (3, 3, 3, 3))
-                h = ops.dense(blk["norm"](h), blk["fc1"], act="gelu")
-                y = ops.dense(h, blk["fc2"], residual=y)
+                y = ops.mlp(blk["norm"](h), blk["fc1"], blk["fc2"], act="gelu", residual=y)
             if collect is not None:
                 collect.append(y)
         return y
