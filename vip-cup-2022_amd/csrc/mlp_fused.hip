@@ -7,9 +7,10 @@
 // against 1.4 GB for x + residual + y.
 //
 // Structure (same operand routing as pw_gemm_kernel in conv_igemm.hip):
-//   * BOTH weight matrices live in LDS for the whole kernel (fragment-ordered rows, odd 16-byte row stride:
-//     conflict-free ds_read_b128); 155 KB for C = 96 / hidden 384, so one 8-wave workgroup per CU;
-//   * a wave owns 64 tokens: their activation fragments (the MFMA B operand: lane = token, 8 consecutive channels =
+//   * BOTH weight matrices live in LDS for the whole kernel (fragment-ordered rows, row stride 32 mod 64 bytes:
+//     conflict-free ds_read_b128); 159 KB for C = 96 / hidden 384, so one workgroup per CU
+//     (16 waves);
+//   * a wave owns 32 tokens: their activation fragments (the MFMA B operand: lane = token, 8 consecutive channels =
 //     one 16-byte run of the row) are loaded global -> VGPR once per tile;
 //   * the hidden layer is produced 32 channels at a time: H^T = W1 X^T (bias as the MFMA C operand), activation in
 //     packed fp32, and - because the weight rows are interleaved so that a lane ends up holding 8 CONSECUTIVE hidden
@@ -42,14 +43,13 @@ __device__ __forceinline__ int frag_channel(int j) {
     return (j & ~31) + (r >> 2) * 8 + t * 4 + (r & 3);
 }
 
-template <int CK, int ACT>
-__global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpArgs a) {
-    constexpr int C = 32 * CK, PT = 4, NCT = C / 16;
+template <int CK, int ACT, int PT>
+__global__ __launch_bounds__(2048 / PT, 1) void mlp_fused_kernel(MlpArgs a) {
+    constexpr int C = 32 * CK, NCT = C / 16, NTHR = 2048 / PT;   // 512 tokens per workgroup: 8 waves x 64 or 16 x 32
     constexpr unsigned OOB = 0xFFFFFFF0u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* w1s = smem;
     char* w2s = smem + a.Hd * a.s1;
-    float* b1s = reinterpret_cast<float*>(w2s + C * a.s2);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
@@ -58,33 +58,33 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpArgs a) {
         const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, (unsigned)(2L * a.Hd * a.ldw1), 0x00020000);
         const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, (unsigned)(2L * C * a.ldw2), 0x00020000);
         constexpr int cpr1 = CK * 4;
-        for (int i = tid; i < a.Hd * cpr1; i += 512) {
+        for (int i = tid; i < a.Hd * cpr1; i += NTHR) {
             const int j = i / cpr1, c = i - j * cpr1;
             const uint4 v = __builtin_bit_cast(
                 uint4, __builtin_amdgcn_raw_buffer_load_b128(r1, (unsigned)((frag_channel(j) * a.ldw1 + c * 8) * 2), 0, 0));
             *reinterpret_cast<uint4*>(w1s + j * a.s1 + c * 16) = v;
         }
         const int cpr2 = a.Hd >> 3;
-        for (int i = tid; i < C * cpr2; i += 512) {
+        for (int i = tid; i < C * cpr2; i += NTHR) {
             const int j = i / cpr2, c = i - j * cpr2;
             const uint4 v = __builtin_bit_cast(
                 uint4, __builtin_amdgcn_raw_buffer_load_b128(r2, (unsigned)((frag_channel(j) * a.ldw2 + c * 8) * 2), 0, 0));
             *reinterpret_cast<uint4*>(w2s + j * a.s2 + c * 16) = v;
         }
-        for (int i = tid; i < a.Hd; i += 512) b1s[i] = a.b1 ? a.b1[i] : 0.f;
     }
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (unsigned)a.res_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (unsigned)a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b1, 0, a.b1 ? (unsigned)(a.Hd * 4) : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b2, 0, a.b2 ? (unsigned)(C * 4) : 0u, 0x00020000);
     const char* w1l = w1s + l15 * a.s1 + lq * 16;
     const char* w2l = w2s + l15 * a.s2 + lq * 16;
     const int nq = a.Hd >> 5;
 
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const int m0 = tile * 512 + wave * 64;
+        const int m0 = tile * 512 + wave * (16 * PT);
         U4H8 xf[CK][PT];
 #pragma unroll
         for (int ks = 0; ks < CK; ++ks)
@@ -104,13 +104,13 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpArgs a) {
             for (int p = 0; p < PT; ++p) acc2[ct][p] = bv;
         }
 
-#pragma unroll 2
-        for (int q = 0; q < nq; ++q) {
-            // hidden slice q: H^T[32 x 64 tokens] = W1[32q.., :] . X^T + b1
-            f32x4 acc1[2][PT];
+        // hidden slice q: H^T[32 x 64 tokens] = W1[32q.., :] . X^T + b1
+        auto gemm1 = [&](int q, f32x4 (&acc1)[2][PT]) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(b1s + q * 32 + lq * 8 + t * 4);
+                // b1 from global (L1-resident, 4 distinct addresses per wave): LDS is full to the last KB
+                const f32x4 bv = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb1, (unsigned)((q * 32 + lq * 8 + t * 4) * 4), 0, 0));
 #pragma unroll
                 for (int p = 0; p < PT; ++p) acc1[t][p] = bv;
             }
@@ -124,8 +124,9 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpArgs a) {
                     for (int p = 0; p < PT; ++p)
                         acc1[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf.h, xf[ks][p].h, acc1[t][p], 0, 0, 0);
                 }
-            // activation; the packed result is the B operand (k = 8*lq + j <-> hidden channel 32q + 8*lq + j)
-            U4H8 hf[PT];
+        };
+        // activation; the packed result is the B operand (k = 8*lq + j <-> hidden channel 32q + 8*lq + j)
+        auto act_pack = [&](const f32x4 (&acc1)[2][PT], U4H8 (&hf)[PT]) {
 #pragma unroll
             for (int p = 0; p < PT; ++p)
 #pragma unroll
@@ -136,7 +137,9 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpArgs a) {
                         hf[p].e[t * 4 + j] = (f16)v.x;
                         hf[p].e[t * 4 + j + 1] = (f16)v.y;
                     }
-            // y^T += W2[:, 32q..32q+31] . H
+        };
+        // y^T += W2[:, 32q..32q+31] . H
+        auto gemm2 = [&](int q, const U4H8 (&hf)[PT]) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 U4H8 wf;
@@ -145,6 +148,16 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpArgs a) {
                 for (int p = 0; p < PT; ++p)
                     acc2[ct][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf.h, hf[p].h, acc2[ct][p], 0, 0, 0);
             }
+        };
+        // (Issuing slice q+1's first-layer MFMAs before slice q's activation - a two-slice software pipeline - was
+        // measured 6 % SLOWER: +42 VGPRs and no overlap gained; the second resident wave already fills the gaps.)
+        U4H8 hf[PT];
+#pragma unroll 1
+        for (int q = 0; q < nq; ++q) {
+            f32x4 h0[2][PT];
+            gemm1(q, h0);
+            act_pack(h0, hf);
+            gemm2(q, hf);
         }
 
         // epilogue: + residual, fp16, 16-byte stores (lane: token m, channels 32*hh + 8*lq .. +7)
@@ -174,12 +187,19 @@ __global__ __launch_bounds__(512, 1) void mlp_fused_kernel(MlpArgs a) {
     }
 }
 
+// LDS row stride for `chunks` 16-byte chunks: == 32 (mod 64) bytes, conflict-free for the fragment read pattern under
+// the ds_read_b128 lane grouping (see launch_pw in conv_igemm.hip)
+static int mlp_stride(int chunks) {
+    while ((chunks & 3) != 2) ++chunks;
+    return chunks * 16;
+}
+
 template <int CK>
 int launch_mlp(MlpArgs a, hipStream_t s) {
     constexpr int C = 32 * CK;
-    a.s1 = ((CK * 4) | 1) * 16;
-    a.s2 = ((a.Hd >> 3) | 1) * 16;
-    const size_t smem = (size_t)a.Hd * a.s1 + (size_t)C * a.s2 + (size_t)a.Hd * 4;
+    a.s1 = mlp_stride(CK * 4);
+    a.s2 = mlp_stride(a.Hd >> 3);
+    const size_t smem = (size_t)a.Hd * a.s1 + (size_t)C * a.s2;
     if (smem > 160 * 1024) return 1;
     a.n_tiles = (a.M + 511) / 512;
     static int n_cu = 0;
@@ -191,12 +211,13 @@ int launch_mlp(MlpArgs a, hipStream_t s) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<CK, VIP_ACT_GELU>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fused_kernel<CK, VIP_ACT_GELU, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
-    hipLaunchKernelGGL((mlp_fused_kernel<CK, VIP_ACT_GELU>), dim3(grid), dim3(512), smem, s, a);
+    // 16 waves x 32 tokens (<= 128 VGPRs, four waves per SIMD) measured 2-8 % ahead of 8 waves x 64 tokens
+    hipLaunchKernelGGL((mlp_fused_kernel<CK, VIP_ACT_GELU, 2>), dim3(grid), dim3(1024), smem, s, a);
     return vip_launch_status("vip_mlp_fused_f16");
 }
 
@@ -204,8 +225,8 @@ int launch_mlp(MlpArgs a, hipStream_t s) {
 
 extern "C" int vip_mlp_fused_supported(int M, int C, int hidden, int act) {
     if (act != VIP_ACT_GELU || (C != 64 && C != 96) || hidden % 32 != 0 || hidden <= 0 || M < 8192) return 0;
-    const long s1 = (((C / 8) | 1) * 16), s2 = (((hidden >> 3) | 1) * 16);
-    return (long)hidden * s1 + (long)C * s2 + (long)hidden * 4 <= 160 * 1024;
+    const long s1 = mlp_stride(C / 8), s2 = mlp_stride(hidden >> 3);
+    return (long)hidden * s1 + (long)C * s2 <= 160 * 1024;
 }
 
 extern "C" int vip_mlp_fused_f16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
