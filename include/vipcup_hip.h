@@ -93,8 +93,8 @@ int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const
  * for narrow token widths whose two weight matrices fit in LDS together.
  *   x [M][ldx] f16 ; w1 [hidden][ldw1] f16 (rows = hidden channels, C contiguous) ; b1 [hidden] f32 or NULL ;
  *   w2 [C][ldw2] f16 (rows = output channels, hidden contiguous) ; b2 [C] f32 or NULL ; residual [M][ldr] or NULL.
- * vip_mlp_fused_supported() says whether a shape is handled (C in {64, 96}, act = GELU, hidden % 32 == 0, both
- * matrices <= 160 KB of LDS, M >= 8192); otherwise use two vip_gemm_bias_act_f16 calls.
+ * vip_mlp_fused_supported() says whether a shape is handled (C in {64, 96} with both matrices <= 160 KB of LDS, or C = 192
+ * with streamed weights; act = GELU, hidden % 32 == 0, M >= 8192); otherwise use two vip_gemm_bias_act_f16 calls.
  * ------------------------------------------------------------------------------------------ */
 int vip_mlp_fused_supported(int M, int C, int hidden, int act);
 int vip_mlp_fused_f16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,

@@ -168,9 +168,10 @@ def test_dense_pointwise_modes(M, K, N, mode, report):
     check(report, f"dense-pointwise {mode} {M}x{K}x{N}", got, ref)
 
 
-# fused MLP (hidden tensor in registers): both supported widths, M tails, with/without residual, vs two fp32 denses
+# fused MLP (hidden tensor in registers): LDS-resident (C 64/96) and streamed (C 192) weights, M tails, with/without residual, vs two fp32 denses
 @pytest.mark.parametrize("M,C,hid,use_res", [(8192, 96, 384, True), (20011, 96, 384, False), (9000, 64, 256, True),
-                                             (8192 + 513, 64, 192, True)])
+                                             (8192 + 513, 64, 192, True), (9001, 192, 768, True),
+                                             (10000, 192, 384, True)])
 def test_mlp_fused(M, C, hid, use_res, report):
     ops = _ops()
     from vipcup_amd import _abi

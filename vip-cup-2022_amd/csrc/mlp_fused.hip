@@ -1,4 +1,4 @@
-// Fused two-layer MLP   y = W2 . act(W1 . x + b1) + b2 (+ residual)   for narrow token widths (C = 64 / 96).
+// Fused two-layer MLP   y = W2 . act(W1 . x + b1) + b2 (+ residual)   for narrow token widths (C = 64 / 96 / 128 / 192).
 //
 // Replaces the Dense -> GELU -> Dense (+Add) tail of tfimm's ConvNeXtBlock (convnext.py:200-229, layer-scale gamma
 // folded into W2/b2 by the host) and of the GCViT / ViT MLP (gcvit/layers/feature.py:20-22,
@@ -221,11 +221,193 @@ int launch_mlp(MlpArgs a, hipStream_t s) {
     return vip_launch_status("vip_mlp_fused_f16");
 }
 
+
+// ---- C = 128 / 192: the two weight matrices (4C x C and C x 4C) no longer fit in LDS together, so they are STREAMED:
+// per 32-channel hidden slice the workgroup stages W1[32q.., :] and W2[:, 32q..] (24 KB at C = 192) into a
+// double-buffered LDS image (global -> VGPR one slice ahead, ds_write after the slice's math, one barrier per slice)
+// while x (32 tokens per wave, 8 waves) and the y accumulators stay in registers for all 4C/32 slices.  The weights
+// come from L2 (2.3 KB per token at C = 192 against 1.15 KB of HBM traffic); the hidden tensor never exists in memory.
+template <int CK, int ACT>
+__global__ __launch_bounds__(512, 1) void mlp_stream_kernel(MlpArgs a) {
+    constexpr int C = 32 * CK, PT = 2, NCT = C / 16, NTHR = 512;
+    constexpr int W_IT = C / 64;                    // 16-byte weight chunks staged per thread per slice (8C / 512)
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int stage_bytes = 32 * a.s1 + C * a.s2;   // W1 slice [32][s1] then W2 slice [C][s2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (unsigned)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (unsigned)a.res_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (unsigned)a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b1, 0, a.b1 ? (unsigned)(a.Hd * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b2, 0, a.b2 ? (unsigned)(C * 4) : 0u, 0x00020000);
+
+    // staging plan of this thread: chunk idx = tid + 512 i; the first 4C chunks are the W1 slice, the rest the W2 slice.
+    // Plain pointers (one load instruction per chunk whichever matrix it comes from: a `is_w1 ? load(w1) : load(w2)`
+    // would be two predicated loads with a wait each)
+    const char* w_ptr[W_IT];   // source of slice 0
+    unsigned w_step[W_IT];     // bytes between consecutive slices
+    int w_dst[W_IT];           // byte offset inside a stage
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int idx = tid + NTHR * i;
+        if (idx < 4 * C) {
+            const int row = idx / (C / 8), c = idx - row * (C / 8);
+            w_ptr[i] = reinterpret_cast<const char*>(a.w1) + ((long)frag_channel(row) * a.ldw1 + c * 8) * 2;
+            w_step[i] = (unsigned)(32 * a.ldw1 * 2);
+            w_dst[i] = row * a.s1 + c * 16;
+        } else {
+            const int j = idx - 4 * C, row = j >> 2, c = j & 3;
+            w_ptr[i] = reinterpret_cast<const char*>(a.w2) + ((long)frag_channel(row) * a.ldw2 + c * 8) * 2;
+            w_step[i] = 64u;
+            w_dst[i] = 32 * a.s1 + row * a.s2 + c * 16;
+        }
+    }
+    uint4 wst[W_IT];
+    auto load_w = [&](int q) {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) wst[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + (size_t)q * w_step[i]);
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * stage_bytes + w_dst[i]) = wst[i];
+    };
+
+    const int nq = a.Hd >> 5;
+    load_w(0);
+    store_w(0);
+    __syncthreads();
+    int buf = 0;
+
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int m0 = tile * (NTHR / 64 * 16 * PT) + wave * (16 * PT);
+        U4H8 xf[CK][PT];
+#pragma unroll
+        for (int ks = 0; ks < CK; ++ks)
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int m = m0 + p * 16 + l15;
+                xf[ks][p].u = __builtin_bit_cast(
+                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, m < a.M ? (unsigned)((m * a.ldx + ks * 32 + lq * 8) * 2) : OOB, 0, 0));
+            }
+        f32x4 acc2[NCT][PT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const f32x4 bv = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb2, (unsigned)(((ct >> 1) * 32 + lq * 8 + (ct & 1) * 4) * 4), 0, 0));
+#pragma unroll
+            for (int p = 0; p < PT; ++p) acc2[ct][p] = bv;
+        }
+
+#pragma unroll 1
+        for (int q = 0; q < nq; ++q) {
+            load_w(q + 1 < nq ? q + 1 : 0);          // next slice (slice 0 of the next tile after the last one)
+            __builtin_amdgcn_sched_barrier(0);
+            const char* w1l = smem + buf * stage_bytes + l15 * a.s1 + lq * 16;
+            const char* w2l = smem + buf * stage_bytes + 32 * a.s1 + l15 * a.s2 + lq * 16;
+            f32x4 acc1[2][PT];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 bv = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb1, (unsigned)((q * 32 + lq * 8 + t * 4) * 4), 0, 0));
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc1[t][p] = bv;
+            }
+#pragma unroll
+            for (int ks = 0; ks < CK; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    U4H8 wf;
+                    wf.u = *reinterpret_cast<const uint4*>(w1l + t * 16 * a.s1 + ks * 64);
+#pragma unroll
+                    for (int p = 0; p < PT; ++p)
+                        acc1[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf.h, xf[ks][p].h, acc1[t][p], 0, 0, 0);
+                }
+            U4H8 hf[PT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const f32x2 v = vip_act2<ACT>((f32x2){acc1[t][p][j], acc1[t][p][j + 1]});
+                        hf[p].e[t * 4 + j] = (f16)v.x;
+                        hf[p].e[t * 4 + j + 1] = (f16)v.y;
+                    }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                U4H8 wf;
+                wf.u = *reinterpret_cast<const uint4*>(w2l + ct * 16 * a.s2);
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    acc2[ct][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf.h, hf[p].h, acc2[ct][p], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            store_w(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int m = m0 + p * 16 + l15;
+            const bool ok = m < a.M;
+#pragma unroll
+            for (int hh = 0; hh < CK; ++hh) {
+                const int n = hh * 32 + lq * 8;
+                U4H8 r;
+                r.u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                    rr, ok ? (unsigned)((m * a.ldr + n) * 2) : OOB, 0, 0));
+                U4H8 o;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const f32x4 av = acc2[2 * hh + (j >> 2)][p];
+                    const f32x2 v = (f32x2){av[j & 3], av[(j & 3) + 1]} + (f32x2){(float)r.e[j], (float)r.e[j + 1]};
+                    o.e[j] = (f16)v.x;
+                    o.e[j + 1] = (f16)v.y;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o.u), ry,
+                    ok ? (unsigned)((m * a.ldy + n) * 2) : OOB, 0, 0);
+            }
+        }
+    }
+}
+
+template <int CK>
+int launch_mlp_stream(MlpArgs a, hipStream_t s) {
+    constexpr int C = 32 * CK;
+    a.s1 = mlp_stride(C / 8);
+    a.s2 = mlp_stride(4);
+    const size_t smem = 2 * ((size_t)32 * a.s1 + (size_t)C * a.s2);
+    a.n_tiles = (a.M + 255) / 256;
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_stream_kernel<CK, VIP_ACT_GELU>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
+    hipLaunchKernelGGL((mlp_stream_kernel<CK, VIP_ACT_GELU>), dim3(grid), dim3(512), smem, s, a);
+    return vip_launch_status("vip_mlp_fused_f16(stream)");
+}
+
 }  // namespace
 
 extern "C" int vip_mlp_fused_supported(int M, int C, int hidden, int act) {
-    if (act != VIP_ACT_GELU || (C != 64 && C != 96) || hidden % 32 != 0 || hidden <= 0 || M < 8192) return 0;
-    const long s1 = mlp_stride(C / 8), s2 = mlp_stride(hidden >> 3);
+    if (act != VIP_ACT_GELU || hidden % 32 != 0 || hidden <= 0 || M < 8192) return 0;
+    if (C == 192) return 1;   // streamed weights (C = 128 is wired up too but measured slower than two GEMMs: not offered)
+    if (C != 64 && C != 96) return 0;
+    const long s1 = mlp_stride(C / 8), s2 = mlp_stride(hidden >> 3);      // LDS-resident weights
     return (long)hidden * s1 + (long)C * s2 <= 160 * 1024;
 }
 
@@ -252,6 +434,8 @@ extern "C" int vip_mlp_fused_f16(const void* x, const void* w1, const float* b1,
     int st = 1;
     if (C == 64) st = launch_mlp<2>(a, (hipStream_t)stream);
     else if (C == 96) st = launch_mlp<3>(a, (hipStream_t)stream);
+    else if (C == 128) st = launch_mlp_stream<4>(a, (hipStream_t)stream);
+    else if (C == 192) st = launch_mlp_stream<6>(a, (hipStream_t)stream);
     VIP_REQUIRE(st != 1, VIP_ERR_UNSUPPORTED, "vip_mlp_fused_f16: weights do not fit in LDS");
     return st;
 }
