@@ -138,6 +138,7 @@ def main():
             line["detail"] = extra
         print(json.dumps(line))
     if dist is not None:
+        dist.barrier()                      # rank 0 is still in its instrumented step / JSON line: leave together
         dist.destroy_process_group()
 
 

@@ -86,7 +86,9 @@ int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const
                           int act_pre, int act_post, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Fused two-layer MLP:  y[M,C] = W2 . act(W1 . x + b1) + b2 (+ residual), hidden tensor never written to memory.
+ * Fused two-layer MLP:  y[M,C] = W2 . act(W1 . LN(x) + b1) + b2 (+ residual), hidden tensor never written to memory.
+ * LN = the LayerNormalization in front of the MLP (convnext.py:199 `norm`, gcvit block `norm2`, ViT `norm2`) when
+ * ln_gamma/ln_beta [C] f32 are given (both NULL: x is used as is).
  * Replaces Dense -> GELU -> Dense (-> layer-scale, folded by the caller) -> Add of
  *   tfimm/architectures/convnext.py:200-229, gcvit/layers/feature.py:20-22 (Mlp),
  *   tfimm/layers/transformers.py:192-205 (MLP)
@@ -97,9 +99,9 @@ int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const
  * with streamed weights; act = GELU, hidden % 32 == 0, M >= 8192); otherwise use two vip_gemm_bias_act_f16 calls.
  * ------------------------------------------------------------------------------------------ */
 int vip_mlp_fused_supported(int M, int C, int hidden, int act);
-int vip_mlp_fused_f16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
-                      const void* residual, void* y, int M, int C, int hidden, int ldx, int ldw1, int ldw2,
-                      int ldy, int ldr, int act, void* stream);
+int vip_mlp_fused_f16(const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w1,
+                      const float* b1, const void* w2, const float* b2, const void* residual, void* y, int M, int C,
+                      int hidden, int ldx, int ldw1, int ldw2, int ldy, int ldr, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Depthwise Conv2D k x k (+bias)(+act).  Replaces tf.keras.layers.DepthwiseConv2D:

@@ -169,29 +169,36 @@ def test_dense_pointwise_modes(M, K, N, mode, report):
 
 
 # fused MLP (hidden tensor in registers): LDS-resident (C 64/96) and streamed (C 192) weights, M tails, with/without residual, vs two fp32 denses
+@pytest.mark.parametrize("use_ln", [False, True])
 @pytest.mark.parametrize("M,C,hid,use_res", [(8192, 96, 384, True), (20011, 96, 384, False), (9000, 64, 256, True),
                                              (8192 + 513, 64, 192, True), (9001, 192, 768, True),
                                              (10000, 192, 384, True)])
-def test_mlp_fused(M, C, hid, use_res, report):
+def test_mlp_fused(M, C, hid, use_res, use_ln, report):
     ops = _ops()
     from vipcup_amd import _abi
     assert _abi.lib().vip_mlp_fused_supported(M, C, hid, 3)
     g = torch.Generator().manual_seed(M + C + hid)
-    x = h(torch.randn(M, C, generator=g))
+    x = h(torch.randn(M, C, generator=g) * 1.5 + 0.3)
     w1 = h(torch.randn(C, hid, generator=g) / math.sqrt(C))
     b1 = torch.randn(hid, generator=g) * 0.1
     w2 = h(torch.randn(hid, C, generator=g) / math.sqrt(hid))
     b2 = torch.randn(C, generator=g) * 0.1
     res = h(torch.randn(M, C, generator=g)) if use_res else None
-    ref = R.dense(R.act(R.dense(x, w1, b1), "gelu"), w2, b2)
+    ln = None
+    xin = x
+    if use_ln:
+        lg, lb = torch.randn(C, generator=g) * 0.2 + 1, torch.randn(C, generator=g) * 0.1
+        ln = (lg.cuda(), lb.cuda(), 1e-6)
+        xin = R.layernorm(x, lg, lb, 1e-6)
+    ref = R.dense(R.act(R.dense(xin, w1, b1), "gelu"), w2, b2)
     if use_res:
         ref = ref + res
     got = ops.mlp(dev(x), ops.make_dense_weight(w1, b1), ops.make_dense_weight(w2, b2), act="gelu",
-                  residual=None if res is None else dev(res))
+                  residual=None if res is None else dev(res), ln=ln)
     torch.cuda.synchronize()
-    # the hidden activations are rounded to fp16 before the second GEMM on both paths of the product; against the
-    # fp32 oracle that is one extra fp16 rounding inside a K = hid dot product
-    check(report, f"mlp_fused M{M} C{C} hid{hid} res{use_res}", got, ref, tol=3e-3)
+    # the normalised input and the hidden activations are rounded to fp16 (as on the unfused path of the product);
+    # against the fp32 oracle that is one extra fp16 rounding inside each dot product
+    check(report, f"mlp_fused M{M} C{C} hid{hid} res{use_res} ln{use_ln}", got, ref, tol=4e-3)
 
 
 @pytest.mark.parametrize("k,s,C,H", [(3, 1, 64, 14), (3, 2, 72, 15), (5, 1, 40, 12), (5, 2, 48, 13), (7, 1, 96, 11)])

@@ -110,6 +110,25 @@ union U4H8 {
     f16 e[8];
 };
 
+// All-reduce (sum) over aligned groups of `lanes` consecutive lanes (8, 16, 32 or 64).  The first four steps are DPP
+// adds inside a 16-lane row (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: one VALU instruction each, no LDS
+// round trip); only the steps across rows use ds_bpermute (__shfl_xor).  A LayerNorm row is two dependent reductions,
+// and with bpermute for every step that chain - not memory - set the kernel's rate.
+template <int CTRL>
+__device__ __forceinline__ float vip_dpp_add(float v) {
+    const int iv = __builtin_bit_cast(int, v);
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float group_allreduce_sum(float v, int lanes) {
+    v = vip_dpp_add<0xB1>(v);                 // quad_perm [1,0,3,2]
+    v = vip_dpp_add<0x4E>(v);                 // quad_perm [2,3,0,1]
+    v = vip_dpp_add<0x141>(v);                // row_half_mirror: 8 lanes
+    if (lanes >= 16) v = vip_dpp_add<0x140>(v);   // row_mirror: 16 lanes
+    if (lanes >= 32) v += __shfl_xor(v, 16, 64);
+    if (lanes >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -29,6 +29,9 @@ struct MlpArgs {
     const float* b2;
     const f16* res;
     f16* y;
+    const float* ln_g;   // optional LayerNorm over C applied to x first (NULL: none)
+    const float* ln_b;
+    float ln_eps;
     int M, Hd;
     int ldx, ldy, ldr, ldw1, ldw2;
     long x_bytes, y_bytes, res_bytes;
@@ -41,6 +44,49 @@ struct MlpArgs {
 __device__ __forceinline__ int frag_channel(int j) {
     const int t = (j >> 4) & 1, r = j & 15;
     return (j & ~31) + (r >> 2) * 8 + t * 4 + (r & 3);
+}
+
+
+// Optional LayerNorm prologue on the activation fragments of one 16-token tile: lane (l15 = token, lq) holds channels
+// 32 ks + 8 lq + 0..7 for ks < CK, so a token's C channels sit in 4 lanes (lq = 0..3): in-lane sums + two cross-row
+// exchanges.  Two-pass mean / variance in fp32 and the same expression as layernorm_kernel (pointwise.hip); the
+// normalised row is rounded to fp16 exactly where the separate LayerNorm launch rounded it.
+template <int CK>
+__device__ __forceinline__ void ln_fragments(U4H8 (&xf)[CK], const float* __restrict__ g, const float* __restrict__ b,
+                                             float eps, int lq) {
+    constexpr int C = 32 * CK;
+    float v[CK][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < CK; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[ks][j] = (float)xf[ks].e[j];
+            sum += v[ks][j];
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < CK; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = v[ks][j] - mean;
+            sq += d * d;
+        }
+    sq += __shfl_xor(sq, 16, 64);
+    sq += __shfl_xor(sq, 32, 64);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+#pragma unroll
+    for (int ks = 0; ks < CK; ++ks) {
+        const float4 g0 = *reinterpret_cast<const float4*>(g + ks * 32 + lq * 8), g1 = *reinterpret_cast<const float4*>(g + ks * 32 + lq * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(b + ks * 32 + lq * 8), b1 = *reinterpret_cast<const float4*>(b + ks * 32 + lq * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[ks].e[j] = (f16)((v[ks][j] - mean) * rstd * gg[j] + bb[j]);
+    }
 }
 
 template <int CK, int ACT, int PT>
@@ -94,6 +140,17 @@ __global__ __launch_bounds__(2048 / PT, 1) void mlp_fused_kernel(MlpArgs a) {
                 xf[ks][p].u = __builtin_bit_cast(
                     uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, m < a.M ? (unsigned)((m * a.ldx + ks * 32 + lq * 8) * 2) : OOB, 0, 0));
             }
+        if (a.ln_g) {   // workgroup-uniform
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                U4H8 col[CK];
+#pragma unroll
+                for (int ks = 0; ks < CK; ++ks) col[ks] = xf[ks][p];
+                ln_fragments<CK>(col, a.ln_g, a.ln_b, a.ln_eps, lq);
+#pragma unroll
+                for (int ks = 0; ks < CK; ++ks) xf[ks][p] = col[ks];
+            }
+        }
         // y accumulators start at b2 (lane: channels 32*hh + 8*lq + 4*t + 0..3 for tile 2*hh + t)
         f32x4 acc2[NCT][PT];
 #pragma unroll
@@ -292,6 +349,17 @@ __global__ __launch_bounds__(512, 1) void mlp_stream_kernel(MlpArgs a) {
                 xf[ks][p].u = __builtin_bit_cast(
                     uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, m < a.M ? (unsigned)((m * a.ldx + ks * 32 + lq * 8) * 2) : OOB, 0, 0));
             }
+        if (a.ln_g) {   // workgroup-uniform
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                U4H8 col[CK];
+#pragma unroll
+                for (int ks = 0; ks < CK; ++ks) col[ks] = xf[ks][p];
+                ln_fragments<CK>(col, a.ln_g, a.ln_b, a.ln_eps, lq);
+#pragma unroll
+                for (int ks = 0; ks < CK; ++ks) xf[ks][p] = col[ks];
+            }
+        }
         f32x4 acc2[NCT][PT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
@@ -411,10 +479,12 @@ extern "C" int vip_mlp_fused_supported(int M, int C, int hidden, int act) {
     return (long)hidden * s1 + (long)C * s2 <= 160 * 1024;
 }
 
-extern "C" int vip_mlp_fused_f16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
-                                 const void* residual, void* y, int M, int C, int hidden, int ldx, int ldw1, int ldw2,
-                                 int ldy, int ldr, int act, void* stream) {
+extern "C" int vip_mlp_fused_f16(const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w1,
+                                 const float* b1, const void* w2, const float* b2, const void* residual, void* y, int M,
+                                 int C, int hidden, int ldx, int ldw1, int ldw2, int ldy, int ldr, int act, void* stream) {
     VIP_REQUIRE(x && w1 && w2 && y, VIP_ERR_BAD_ARG, "vip_mlp_fused_f16: null pointer");
+    VIP_REQUIRE((ln_gamma == nullptr) == (ln_beta == nullptr), VIP_ERR_BAD_ARG,
+                "vip_mlp_fused_f16: ln_gamma and ln_beta must both be given or both be NULL");
     VIP_REQUIRE(M > 0 && C > 0 && hidden > 0, VIP_ERR_BAD_ARG, "vip_mlp_fused_f16: non-positive dimension");
     VIP_REQUIRE(vip_mlp_fused_supported(M, C, hidden, act), VIP_ERR_UNSUPPORTED,
                 "vip_mlp_fused_f16: unsupported shape/activation (C=%d hidden=%d act=%d M=%d); use two vip_gemm_bias_act_f16 calls",
@@ -426,6 +496,7 @@ extern "C" int vip_mlp_fused_f16(const void* x, const void* w1, const float* b1,
     MlpArgs a;
     a.x = (const f16*)x; a.w1 = (const f16*)w1; a.b1 = b1; a.w2 = (const f16*)w2; a.b2 = b2;
     a.res = (const f16*)residual; a.y = (f16*)y;
+    a.ln_g = ln_gamma; a.ln_b = ln_beta; a.ln_eps = ln_eps;
     a.M = M; a.Hd = hidden; a.ldx = ldx; a.ldy = ldy; a.ldr = ldr; a.ldw1 = ldw1; a.ldw2 = ldw2;
     a.x_bytes = 2L * M * ldx; a.y_bytes = 2L * M * ldy; a.res_bytes = 2L * M * ldr;
     VIP_REQUIRE(a.x_bytes < 0xFFFFFFF0L && a.y_bytes < 0xFFFFFFF0L && a.res_bytes < 0xFFFFFFF0L, VIP_ERR_UNSUPPORTED,

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
             sum += v[i][j];
         }
     }
-    for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum = group_allreduce_sum(sum, lpr);
     const float mean = sum / (float)C;
     float sq = 0.f;
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
             }
         }
     }
-    for (int o = lpr >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    sq = group_allreduce_sum(sq, lpr);
     const float rstd = rsqrtf(sq / (float)C + eps);
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {

@@ -127,7 +127,7 @@ class _Block:
         att = ops.window_attention(qkv, q_global if self.global_query else None, self.table, self.heads, self.ws,
                                    hd ** -0.5)
         x = ops.dense(att, self.proj, residual=x)            # x + attn   (gamma1 = 1, block.py:54-56,79)
-        return ops.mlp(self.n2(x), self.fc1, self.fc2, act="gelu", residual=x)   # x + mlp    (:80)
+        return ops.mlp(x, self.fc1, self.fc2, act="gelu", residual=x, ln=(self.n2.g, self.n2.b, LN_EPS))   # x + mlp(norm2(x))  (:80)
 
 
 class GCViT:

@@ -183,9 +183,10 @@ def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Op
     return out
 
 
-def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual: Optional[torch.Tensor] = None):
-    """``fc2(act(fc1(x))) (+ residual)`` over the last axis.  One fused launch (hidden tensor stays in registers) when
-    the C ABI supports the shape, otherwise two Dense launches - same arithmetic either way."""
+def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual: Optional[torch.Tensor] = None, ln=None):
+    """``fc2(act(fc1(LN(x)))) (+ residual)`` over the last axis; ``ln = (gamma, beta, eps)`` or None.  One fused launch
+    (LayerNorm in the prologue, hidden tensor in registers) when the C ABI supports the shape, otherwise LayerNorm +
+    two Dense launches - same arithmetic either way."""
     _chk16(x, "mlp.x")
     C_ = x.shape[-1]
     M = x.numel() // C_
@@ -196,17 +197,20 @@ def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual:
         if residual is not None:
             _chk16(residual, "mlp.residual")
             assert residual.shape == out.shape
+        g, b, eps = (ln[0], ln[1], float(ln[2])) if ln is not None else (None, None, 0.0)
         tok = None
         if _PROF is not None:
             tok = _PROF.start("conv_igemm_kernel", 4.0 * M * C_ * hid,
                               2.0 * (M * C_ * (3 if residual is not None else 2) + fc1.w.numel() + fc2.w.numel()))
-        st = _abi.lib().vip_mlp_fused_f16(_p(x), _p(fc1.w), _p(fc1.bias), _p(fc2.w), _p(fc2.bias), _p(residual), _p(out),
-                                          M, C_, hid, C_, fc1.ldw, fc2.ldw, C_, C_ if residual is not None else 0,
-                                          _act(act), _stream())
+        st = _abi.lib().vip_mlp_fused_f16(_p(x), _p(g), _p(b), eps, _p(fc1.w), _p(fc1.bias), _p(fc2.w), _p(fc2.bias),
+                                          _p(residual), _p(out), M, C_, hid, C_, fc1.ldw, fc2.ldw, C_,
+                                          C_ if residual is not None else 0, _act(act), _stream())
         if tok is not None:
             _PROF.stop(tok)
         _abi.check(st, "vip_mlp_fused_f16")
         return out
+    if ln is not None:
+        x = layernorm(x, ln[0], ln[1], float(ln[2]))
     return dense(dense(x, fc1, act=act), fc2, residual=residual)
 
 

@@ -114,7 +114,7 @@ class ViT:
             qkv = ops.dense(blk["n1"](t), blk["qkv"])
             att = ops.mhsa(qkv, cfg.nb_heads, scale)
             t = ops.dense(att, blk["proj"], residual=t)
-            t = ops.mlp(blk["n2"](t), blk["fc1"], blk["fc2"], act="gelu", residual=t)
+            t = ops.mlp(t, blk["fc1"], blk["fc2"], act="gelu", residual=t, ln=(blk["n2"].g, blk["n2"].b, LN_EPS))
             if collect is not None:
                 collect.append(t)
         return self.norm(t)
@@ -210,7 +210,8 @@ class ConvNeXt:
                 y = ops.conv2d(ln(y), cw, stride=2)                               # 2x2/2 VALID (convnext.py:260-267)
             for blk in st["blocks"]:                                              # ConvNeXtBlock.call (:220-229)
                 h = ops.dwconv2d(y, blk["dw"], blk["dwb"], 7, 1, (3, 3, 3, 3))
-                y = ops.mlp(blk["norm"](h), blk["fc1"], blk["fc2"], act="gelu", residual=y)
+                n = blk["norm"]                                                   # LN fused into the MLP launch
+                y = ops.mlp(h, blk["fc1"], blk["fc2"], act="gelu", residual=y, ln=(n.g, n.b, LN_EPS))
             if collect is not None:
                 collect.append(y)
         return y
