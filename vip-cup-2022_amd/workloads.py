@@ -138,6 +138,8 @@ def build(name: str, batch: int, rank: int = 0, world: int = 1) -> Workload:
         members = zoo.ENSEMBLE
     elif name == "ensemble8":
         members = zoo.ENSEMBLE8
+    elif name == "ensemble4":
+        members = zoo.ENSEMBLE4
     else:
         members = [name]
     return Workload(name, members, batch, rank, world)

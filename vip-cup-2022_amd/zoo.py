@@ -64,6 +64,8 @@ ENSEMBLE: List[str] = ["convnext_tiny_in22k", "resnest50", "gcvit_tiny", "effici
                        "eca_nfnet_l0", "resnet_rs50"]
 # BASELINE.json config 5 asks for 8 members: the shipped 7 + a tfimm ViT
 ENSEMBLE8: List[str] = ENSEMBLE + ["vit_small_patch16_224"]
+# BASELINE.json config 4: ResNet-RS + GCViT + 2x tfimm ViT
+ENSEMBLE4: List[str] = ["resnet_rs50", "gcvit_tiny", "vit_tiny_patch16_224", "vit_small_patch16_224"]
 
 
 _HEADS = None
