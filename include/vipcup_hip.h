@@ -104,6 +104,19 @@ int vip_mlp_fused_f16(const void* x, const float* ln_gamma, const float* ln_beta
                       int hidden, int ldx, int ldw1, int ldw2, int ldy, int ldr, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Squeeze-excite gate in one launch:  gate[b,:] = act2(W2 . act1(W1 . mean_hw(x[b]) + b1) + b2).
+ * Replaces GlobalAveragePooling2D -> Conv1x1/Dense(+act) -> Conv1x1/Dense(+sigmoid) of
+ *   kecam common_layers.py:311-332 (se_module), resnet_rs_model.py:145-183 (SE),
+ *   gcvit/layers/feature.py:46-70 (SE), kecam resnest/resnest.py:44-57 (split-attention gate).
+ *   x [B][HW][ldx] f16 ; w1 [Cr][ldw1] f16, b1 [Cr] f32 or NULL ; w2 [Cout][ldw2] f16, b2 [Cout] f32 or NULL ;
+ *   gate [B][Cout] f16.  C, Cr multiples of 8 (pad with zero weights).  The pooled and hidden vectors are rounded
+ *   to fp16 exactly where vip_global_avgpool_f16 + 2 x vip_gemm_bias_act_f16 round them.
+ * ------------------------------------------------------------------------------------------ */
+int vip_se_gate_f16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* gate,
+                    int B, int HW, int C, int ldx, int Cr, int ldw1, int Cout, int ldw2, int act1, int act2,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Depthwise Conv2D k x k (+bias)(+act).  Replaces tf.keras.layers.DepthwiseConv2D:
  *   gcvit/layers/feature.py:93,133 ; tfimm/architectures/convnext.py:192-198 ;
  *   kecam efficientnet_v2.py:85 (common_layers.py:251-265).

@@ -201,6 +201,38 @@ def test_mlp_fused(M, C, hid, use_res, use_ln, report):
     check(report, f"mlp_fused M{M} C{C} hid{hid} res{use_res} ln{use_ln}", got, ref, tol=4e-3)
 
 
+# squeeze-excite gate in one launch vs pool -> dense -> dense of the oracle: wide/narrow C, Cr padded to 8, HW not a
+# multiple of the pixel-group count, more channels than threads
+@pytest.mark.parametrize("B,H,W,C,Cr,Co,act1", [(5, 7, 7, 1632, 72, 1632, "silu"), (3, 56, 56, 192, 8, 192, "silu"),
+                                                (4, 13, 13, 64, 16, 64, "gelu"), (2, 25, 25, 512, 128, 1024, "relu"),
+                                                (2, 7, 7, 4352, 184, 4352, "silu")])
+def test_se_gate(B, H, W, C, Cr, Co, act1, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 7 + C)
+    x = h(torch.randn(B, H, W, C, generator=g) + 0.3)
+    w1 = h(torch.randn(C, Cr, generator=g) / math.sqrt(C) * 3)
+    b1 = torch.randn(Cr, generator=g) * 0.1
+    w2 = h(torch.randn(Cr, Co, generator=g) / math.sqrt(Cr) * 2)
+    b2 = torch.randn(Co, generator=g) * 0.1
+    pooled = h(x.mean(dim=(1, 2)))
+    ref = R.act(R.dense(h(R.act(R.dense(pooled, w1, b1), act1)), w2, b2), "sigmoid")
+    fc1, fc2 = ops.make_dense_weight(w1, b1), ops.make_dense_weight(w2, b2)
+    got = ops.se_gate(dev(x), fc1, fc2, act1, "sigmoid")           # host picks fused / pool + 2 GEMMs by weight size
+    torch.cuda.synchronize()
+    check(report, f"se_gate B{B} {H}x{W} C{C} Cr{Cr}", got, ref)
+    from vipcup_amd import _abi                                     # and the C entry point itself, whatever the size
+    import ctypes as Ct
+    out = torch.empty((B, Co), dtype=torch.float16, device="cuda")
+    xd = dev(x)
+    st = _abi.lib().vip_se_gate_f16(Ct.c_void_p(xd.data_ptr()), Ct.c_void_p(fc1.w.data_ptr()), Ct.c_void_p(fc1.bias.data_ptr()),
+                                    Ct.c_void_p(fc2.w.data_ptr()), Ct.c_void_p(fc2.bias.data_ptr()), Ct.c_void_p(out.data_ptr()),
+                                    B, H * W, C, C, fc1.cout, fc1.ldw, Co, fc2.ldw, ops._act(act1), 4,
+                                    Ct.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    torch.cuda.synchronize()
+    check(report, f"vip_se_gate_f16 B{B} {H}x{W} C{C} Cr{Cr}", out, ref)
+
+
 @pytest.mark.parametrize("k,s,C,H", [(3, 1, 64, 14), (3, 2, 72, 15), (5, 1, 40, 12), (5, 2, 48, 13), (7, 1, 96, 11)])
 def test_dwconv(k, s, C, H, report):
     ops = _ops()

@@ -43,6 +43,7 @@ SIGNATURES = {
     "vip_gemm_bias_act_f16": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "vip_mlp_fused_supported": (_i, [_i, _i, _i, _i]),
     "vip_mlp_fused_f16": (_i, [_vp, _vp, _vp, _f] + [_vp] * 6 + [_i] * 9 + [_vp]),
+    "vip_se_gate_f16": (_i, [_vp] * 6 + [_i] * 10 + [_vp]),
     "vip_dwconv2d_nhwc_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
     "vip_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "vip_pool2d_nhwc_f16": (_i, [_vp, _vp] + [_i] * 13 + [_vp]),

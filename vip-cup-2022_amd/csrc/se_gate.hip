@@ -1,0 +1,136 @@
+// Squeeze-excite gate in ONE launch:  gate[b, :] = act2( W2 . act1( W1 . mean_hw(x[b]) + b1 ) + b2 )
+//
+// Replaces GlobalAveragePooling2D -> Conv1x1/Dense(+act) -> Conv1x1/Dense(+sigmoid) of kecam `se_module`
+// (common_layers.py:311-332), ResNet-RS `SE` (resnet_rs_model.py:145-183), GCViT `SE` (gcvit/layers/feature.py:46-70) and
+// the ResNeSt split-attention gate (resnest.py:44-57).  As three launches (pool, Dense with M = batch, Dense with M =
+// batch) the chain is pure launch latency: the two GEMMs have 256 rows and run on a handful of workgroups while the
+// rest of the chip idles, 50-120 us per block for ~30 us of memory time.  Here one workgroup per image pools its
+// feature map (fp32 partial sums through LDS), then runs the two tiny matrix-vector products out of L2 with the pooled
+// vector in LDS.  Rounding points are those of the three-launch path: the pooled vector and the hidden vector are
+// rounded to fp16 before they are multiplied.
+#include "common.hpp"
+
+namespace {
+
+struct SeArgs {
+    const f16* x;
+    const f16* w1;
+    const float* b1;
+    const f16* w2;
+    const float* b2;
+    f16* gate;
+    int HW, C, ldx, Cr, ldw1, Co, ldw2, ldg;
+    int act1, act2;
+};
+
+constexpr int SE_THREADS = 512;
+
+__global__ __launch_bounds__(SE_THREADS) void se_gate_kernel(SeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C8 = a.C >> 3;
+    const int cw = C8 < SE_THREADS ? C8 : SE_THREADS;    // channel-chunk lanes
+    const int G = SE_THREADS / cw;                       // pixel groups
+    float* part = sm;                                    // [G][C]
+    float* mean = sm + G * a.C;                          // [C]      (fp16-rounded values)
+    float* hid = mean + a.C;                             // [Cr]     (fp16-rounded values)
+    const f16* xb = a.x + (long)blockIdx.x * a.HW * a.ldx;
+
+    // ---- 1. pool: thread = (channel chunk cl (+ k*cw), pixel group pg); 16-byte loads, fp32 sums
+    const int cl = tid % cw, pg = tid / cw;
+    if (pg < G) {
+        for (int c8 = cl; c8 < C8; c8 += cw) {
+            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int p = pg;
+            // eight independent 16-byte loads in flight per lane: one workgroup per CU has to cover the memory latency
+            // by itself (512 lanes x 8 x 16 B = 64 KB outstanding)
+            for (; p + 7 * G < a.HW; p += 8 * G) {
+                U4H8 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u].u = *reinterpret_cast<const uint4*>(xb + (long)(p + u * G) * a.ldx + c8 * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    s[j] += (((float)v[0].e[j] + (float)v[1].e[j]) + ((float)v[2].e[j] + (float)v[3].e[j])) +
+                            (((float)v[4].e[j] + (float)v[5].e[j]) + ((float)v[6].e[j] + (float)v[7].e[j]));
+            }
+            for (; p < a.HW; p += G) {
+                U4H8 v;
+                v.u = *reinterpret_cast<const uint4*>(xb + (long)p * a.ldx + c8 * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += (float)v.e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[pg * a.C + c8 * 8 + j] = s[j];
+        }
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)a.HW;
+    for (int c = tid; c < a.C; c += SE_THREADS) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += part[g * a.C + c];
+        mean[c] = (float)(f16)(s * inv);                 // the three-launch path stores the pooled map as fp16
+    }
+    __syncthreads();
+
+    // ---- 2. hidden = act1(W1 . mean + b1): one output per wave at a time, lanes split the C axis in 16-byte chunks
+    // (four outputs per wave in flight: a single row at a time is one dependent L2 round trip after another)
+    for (int r0 = wave * 4; r0 < a.Cr; r0 += SE_THREADS / 64 * 4) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c8 = lane; c8 < C8; c8 += 64) {
+            U4H8 w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + u < a.Cr ? r0 + u : a.Cr - 1;
+                w[u].u = *reinterpret_cast<const uint4*>(a.w1 + (long)r * a.ldw1 + c8 * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float m = mean[c8 * 8 + j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += (float)w[u].e[j] * m;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float t = wave_reduce_sum(s[u]);
+            if (lane == 0 && r0 + u < a.Cr) hid[r0 + u] = (float)(f16)vip_act(t + (a.b1 ? a.b1[r0 + u] : 0.f), a.act1);
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. gate = act2(W2 . hidden + b2): one output channel per thread (rows of W2 are Cr halfs, contiguous)
+    const int R8 = a.Cr >> 3;
+    for (int c = tid; c < a.Co; c += SE_THREADS) {
+        float s = a.b2 ? a.b2[c] : 0.f;
+#pragma unroll 4
+        for (int r8 = 0; r8 < R8; ++r8) {
+            U4H8 w;
+            w.u = *reinterpret_cast<const uint4*>(a.w2 + (long)c * a.ldw2 + r8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)w.e[j] * hid[r8 * 8 + j];
+        }
+        a.gate[(long)blockIdx.x * a.ldg + c] = (f16)vip_act(s, a.act2);
+    }
+}
+
+}  // namespace
+
+extern "C" int vip_se_gate_f16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* gate,
+                               int B, int HW, int C, int ldx, int Cr, int ldw1, int Cout, int ldw2, int act1, int act2,
+                               void* stream) {
+    VIP_REQUIRE(x && w1 && w2 && gate, VIP_ERR_BAD_ARG, "vip_se_gate_f16: null pointer");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && Cr > 0 && Cout > 0, VIP_ERR_BAD_ARG, "vip_se_gate_f16: non-positive dimension");
+    VIP_REQUIRE((unsigned)act1 <= 4u && (unsigned)act2 <= 4u, VIP_ERR_BAD_ARG, "vip_se_gate_f16: unknown activation code");
+    VIP_REQUIRE(C % 8 == 0 && Cr % 8 == 0 && ldx % 8 == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0, VIP_ERR_ALIGNMENT,
+                "vip_se_gate_f16: C, Cr and the leading dimensions must be multiples of 8 halfs");
+    VIP_REQUIRE(ldx >= C && ldw1 >= C && ldw2 >= Cr, VIP_ERR_BAD_ARG, "vip_se_gate_f16: leading dimension too small");
+    const int C8 = C / 8, cw = C8 < SE_THREADS ? C8 : SE_THREADS, G = SE_THREADS / cw;
+    const size_t smem = ((size_t)G * C + C + Cr) * sizeof(float);
+    VIP_REQUIRE(smem <= 64 * 1024, VIP_ERR_UNSUPPORTED, "vip_se_gate_f16: C=%d too wide", C);
+    SeArgs a;
+    a.x = (const f16*)x; a.w1 = (const f16*)w1; a.b1 = b1; a.w2 = (const f16*)w2; a.b2 = b2; a.gate = (f16*)gate;
+    a.HW = HW; a.C = C; a.ldx = ldx; a.Cr = Cr; a.ldw1 = ldw1; a.Co = Cout; a.ldw2 = ldw2; a.ldg = Cout;
+    a.act1 = act1; a.act2 = act2;
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(SE_THREADS), smem, (hipStream_t)stream, a);
+    return vip_launch_status("vip_se_gate_f16");
+}

@@ -77,9 +77,7 @@ class _ConvBranch:
     def __call__(self, x):
         """returns x + branch(x)"""
         y = ops.dwconv2d(x, self.dw, None, 3, 1, PAD1, act="gelu")
-        s = ops.global_avgpool(y)
-        s = ops.dense(s, self.fc0, act="gelu")
-        s = ops.dense(s, self.fc2, act="sigmoid")
+        s = ops.se_gate(y, self.fc0, self.fc2, "gelu", "sigmoid")
         y = ops.scale_add_act(y, s, None, None)
         return ops.conv2d(y, self.pw, residual=x)
 

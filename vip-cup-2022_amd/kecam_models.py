@@ -155,8 +155,7 @@ class ResNest(_Base):
                 sc = y
             d = ops.conv2d(y, blk["d1"], act="relu")
             lg = ops.conv2d(d, blk["sa1"], pad=PAD1, act="relu")                # [B,H,W,2*hid]
-            a = ops.dense(ops.global_avgpool(lg), blk["sa2"], act="relu")
-            a = ops.dense(a, blk["sa3"], act="sigmoid")
+            a = ops.se_gate(lg, blk["sa2"], blk["sa3"], "relu", "sigmoid")
             d = ops.radix_combine(lg, a, 2)
             if s > 1:
                 d = ops.pool2d(d, 3, 2, PAD1, ops.POOL_AVG_FULL)
@@ -285,8 +284,7 @@ class EfficientNet(_Base):
                 h = ops.conv2d(y, blk["exp"], act=act) if blk["exp"] is not None else y
                 h = ops.dwconv2d(h, blk["dw"][0], blk["dw"][1], k, s, self._pad(h.shape[1:3], k, s), act=act)
                 if blk["se"] is not None:
-                    a = ops.dense(ops.global_avgpool(h), blk["se"][0], act=act)
-                    a = ops.dense(a, blk["se"][1], act="sigmoid")
+                    a = ops.se_gate(h, blk["se"][0], blk["se"][1], act, "sigmoid")
                     h = ops.scale_add_act(h, a, None, None)
                 y = ops.conv2d(h, blk["out"], residual=inp if blk["shortcut"] else None)
             last_of_stage = i + 1 == len(self.blocks) or self.blocks[i + 1]["stage"] != blk["stage"]

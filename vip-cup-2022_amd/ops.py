@@ -214,6 +214,25 @@ def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual:
     return dense(dense(x, fc1, act=act), fc2, residual=residual)
 
 
+def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmoid") -> torch.Tensor:
+    """``act2(fc2(act1(fc1(global_avgpool(x)))))`` -> [B, fc2.cout] fp16.
+
+    One launch (vip_se_gate_f16: a workgroup per image, matrix-vector products out of L2) when the two weight matrices
+    are small - every image re-reads them, so for wide gates (ResNet-RS / ResNeSt: Cr = C/4) the pool + two batched
+    GEMMs are cheaper and are used instead.  Same rounding points either way."""
+    _chk16(x, "se_gate.x")
+    B, H, W, Cc = x.shape
+    assert fc1.groups == 1 and fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1
+    assert fc1.cin == Cc and fc2.cin == fc1.cout, (fc1.cin, Cc, fc2.cin, fc1.cout)
+    if Cc * fc1.cout + fc1.cout * fc2.cout > 256 * 1024:
+        return dense(dense(global_avgpool(x), fc1, act=act1), fc2, act=act2)
+    out = torch.empty((B, fc2.cout), dtype=torch.float16, device=x.device)
+    st = _abi.lib().vip_se_gate_f16(_p(x), _p(fc1.w), _p(fc1.bias), _p(fc2.w), _p(fc2.bias), _p(out), B, H * W, Cc, Cc,
+                                    fc1.cout, fc1.ldw, fc2.cout, fc2.ldw, _act(act1), _act(act2), _stream())
+    _abi.check(st, "vip_se_gate_f16")
+    return out
+
+
 def dwconv2d(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride=1, pad=(0, 0, 0, 0), act=None):
     """Depthwise conv; ``w_khwc`` fp16 ``[k,k,C]``, bias fp32 ``[C]``."""
     _chk16(x, "dwconv2d.x")

@@ -119,9 +119,7 @@ class ResNetRS:
         scale = None
         if self.has_se:
             # SE (:145-183): squeeze -> 1x1 relu -> 1x1 sigmoid
-            sq = ops.global_avgpool(y)
-            sq = ops.dense(sq, blk["se_r"], act="relu")
-            scale = ops.dense(sq, blk["se_e"], act="sigmoid")
+            scale = ops.se_gate(y, blk["se_r"], blk["se_e"], "relu", "sigmoid")
         return ops.scale_add_act(y, scale, shortcut, self.act)
 
     def features(self, x: torch.Tensor, collect=None) -> torch.Tensor:
