@@ -78,6 +78,19 @@ typedef struct vip_conv_desc {
 int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, const void* residual,
                         void* y, const vip_conv_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * vip_conv2d_nhwc_f16 with a squeeze-excite gate folded into the activation load:
+ *   y = epilogue( conv1x1( x[b,h,w,c] * gate[b,c] ) )
+ * gate [B][Cin] f16 (the output of vip_se_gate_f16).  The product is rounded to fp16 once, exactly as
+ * vip_scale_add_act_f16 would have written it, so the result is bit-identical to scale-then-conv without the extra
+ * read+write of the expanded tensor.  Replaces `Multiply()([inputs, se])` + the projection Conv2D of kecam se_module
+ * (common_layers.py:328-332 with efficientnet_v2.py:97-101) and of gcvit/layers/feature.py:66-70,135-137.
+ * Only 1x1 stride-1 ungrouped convolutions whose epilogue is (activation) or (residual [+ReLU]) are accepted
+ * (VIP_ERR_UNSUPPORTED otherwise: scale with vip_scale_add_act_f16, then vip_conv2d_nhwc_f16).
+ * ------------------------------------------------------------------------------------------ */
+int vip_conv2d_gated_nhwc_f16(const void* x, const void* gate, const void* w, const float* bias, const void* residual,
+                              void* y, const vip_conv_desc* d, void* stream);
+
 /* Dense / 1x1 convenience wrapper: C[M,N] = act_post(act_pre(A[M,K] @ W[N,K]^T + bias) + residual).
  * Replaces tf.keras.layers.Dense (gcvit/layers/attention.py:25,33, feature.py:20-22;
  * tfimm/layers/transformers.py:192-205; all classifier heads). */

@@ -111,6 +111,31 @@ def test_conv2d_pointwise_stream(case, report):
     check(report, f"conv2d pointwise-stream {case}", got, ref)
 
 
+# squeeze-excite gate folded into the pointwise conv's activation load == scale_add_act then conv, bit for bit
+@pytest.mark.parametrize("B,H,W,Cin,Cout,use_res", [(3, 14, 14, 672, 112, True), (2, 57, 56, 144, 32, False),
+                                                    (2, 7, 7, 1632, 272, True), (4, 9, 9, 200, 72, False)])
+def test_conv2d_gated(B, H, W, Cin, Cout, use_res, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = h(torch.randn(B, H, W, Cin, generator=g))
+    gate = h(torch.rand(B, Cin, generator=g))
+    w = h(torch.randn(1, 1, Cin, Cout, generator=g) / math.sqrt(Cin))
+    bias = torch.randn(Cout, generator=g) * 0.1
+    res = h(torch.randn(B, H, W, Cout, generator=g)) if use_res else None
+    xs = h(x * gate[:, None, None, :])
+    ref = R.conv2d(xs, w, bias, 1, (0, 0, 0, 0), 1)
+    if use_res:
+        ref = ref + res
+    cw = ops.make_conv_weight(w, bias)
+    xd, gd = dev(x), dev(gate)
+    rd = None if res is None else dev(res)
+    got = ops.conv2d(xd, cw, residual=rd, gate=gd)
+    two = ops.conv2d(ops.scale_add_act(xd, gd, None, None), cw, residual=rd)
+    torch.cuda.synchronize()
+    check(report, f"conv2d gated {B}x{H}x{W}x{Cin}->{Cout}", got, ref)
+    assert torch.equal(got, two), "gated conv differs from scale-then-conv"
+
+
 def test_conv2d_act_post_and_channel_slices(report):
     """act applied after the residual; input/outputs addressed as channel slices of wider tensors."""
     ops = _ops()

@@ -4,9 +4,11 @@ Units/corrections per MI355X_MICROARCH.md (HBM section): both counters are KiB; 
 128-byte requests of wide (16 B/lane) streaming reads at 64 B, so it is doubled; WRITE_SIZE is exact."""
 import collections, csv, glob, json, sys
 
-FAMILIES = {"conv_gemm": ("conv_igemm_kernel", "pw_gemm_kernel", "pwk_gemm_kernel"), "window_attn": ("window_attn_kernel",),
+FAMILIES = {"conv_igemm_kernel": ("conv_igemm_kernel",), "pw_gemm_kernel": ("pw_gemm_kernel",),
+            "pwk_gemm_kernel": ("pwk_gemm_kernel",), "mlp_fused_kernel": ("mlp_fused_kernel",),
+            "mlp_stream_kernel": ("mlp_stream_kernel",), "window_attn_kernel": ("window_attn_kernel",),
             "dwconv": ("dwconv_tile_kernel", "dwconv_kernel"), "layernorm": ("layernorm_kernel",),
-            "scale_add_act": ("scale_add_act_kernel",), "gap": ("gap_kernel",)}
+            "scale_add_act": ("scale_add_act_kernel",), "gap": ("gap_kernel",), "se_gate": ("se_gate_kernel",)}
 
 
 def load(d, counter):

@@ -42,6 +42,8 @@ struct ConvArgs {
     int bias_elems;
     int act_pre, act_post;
     int m_blocks, n_blocks;
+    const f16* gate;   // optional per-image input-channel gate [B][K] (squeeze-excite scale folded into the load); pwk only
+    int gate_hw;       // pixels per image (image index of pixel m = m / gate_hw)
 };
 
 __device__ __forceinline__ int swz_x(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -483,7 +485,7 @@ int launch_pw_k(const ConvArgs& a, int mode, hipStream_t s) {
 // each wave owns 64 pixels and loads their activation fragments global -> VGPR one chunk ahead.  Against the
 // im2col tile kernel this halves LDS traffic (no activation round trip), removes the per-k-tile im2col address
 // arithmetic from the VALU (offsets here are linear in k) and gives each wave a 64 x 128 accumulator tile.
-template <int NG>
+template <int NG, bool GATED>
 __global__ __launch_bounds__(256, 2) void pwk_gemm_kernel(ConvArgs a, int mode) {
     constexpr int PT = 4, NB = 64 * NG, ROWB = 160;          // LDS row: 64 halfs + 32 B pad (stride = 32 mod 64: launch_pw)
     constexpr int STAGE = NB * ROWB;
@@ -533,6 +535,16 @@ __global__ __launch_bounds__(256, 2) void pwk_gemm_kernel(ConvArgs a, int mode) 
         const int m = m0 + p * 16 + l15;
         x_off[p] = m < a.M ? (unsigned)((m * a.ldx + lq * 8) * 2) : 0xFFFF0000u;   // + k bytes stays out of range
     }
+    // squeeze-excite gate folded into the activation operand: x[m, k] * gate[image(m), k], the fp16 product rounded
+    // once - bit-identical to scale_add_act writing x * gate as fp16 and this kernel reading it back
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.gate, 0, GATED ? (unsigned)min((long)0xFFFFFFF0L, 2L * ((a.M + a.gate_hw - 1) / a.gate_hw) * a.K) : 0u, 0x00020000);
+    unsigned g_off[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m0 + p * 16 + l15;
+        g_off[p] = (GATED && m < a.M) ? (unsigned)(((m / a.gate_hw) * a.K + lq * 8) * 2) : 0xFFFF0000u;
+    }
     const int nk = (a.K + 63) >> 6;
 
     uint4 wst[W_IT];
@@ -546,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void pwk_gemm_kernel(ConvArgs a, int mode) 
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + w_lds[i]) = wst[i];
     };
-    U4H8 xf[2][PT];
+    U4H8 xf[2][PT], gf[GATED ? 2 : 1][GATED ? PT : 1];
     auto load_x = [&](int kc, int ks) {
         // weights of the K tail are zero in LDS, but 0 * (Inf/NaN garbage of the next row) is NaN: mask the lanes
         const bool ok = kc * 64 + ks * 32 + lq * 8 < a.K;
@@ -554,6 +566,12 @@ __global__ __launch_bounds__(256, 2) void pwk_gemm_kernel(ConvArgs a, int mode) 
         for (int p = 0; p < PT; ++p)
             xf[ks][p].u = __builtin_bit_cast(
                 uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + kc * 128 + ks * 64 : OOB, 0, 0));
+        if constexpr (GATED) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+                gf[ks][p].u = __builtin_bit_cast(
+                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? g_off[p] + kc * 128 + ks * 64 : OOB, 0, 0));
+        }
     };
 
     f32x4 acc[NG][PT][4];
@@ -578,6 +596,10 @@ __global__ __launch_bounds__(256, 2) void pwk_gemm_kernel(ConvArgs a, int mode) 
 
     auto compute = [&](int buf, int ks) {
         const char* ws = smem + buf * STAGE + l15 * ROWB + lq * 16 + ks * 64;
+        if constexpr (GATED) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) xf[ks][p].h = xf[ks][p].h * gf[ks][p].h;     // 4 x v_pk_mul_f16
+        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             U4H8 wf[4];
@@ -635,7 +657,8 @@ int launch_pwk(const ConvArgs& a0, int mode, hipStream_t s) {
     ConvArgs a = a0;
     a.m_blocks = (a.M + 255) / 256;
     a.n_blocks = (a.Cout_g + 64 * NG - 1) / (64 * NG);
-    hipLaunchKernelGGL((pwk_gemm_kernel<NG>), dim3((unsigned)(a.m_blocks * a.n_blocks)), dim3(256), 0, s, a, mode);
+    if (a.gate) hipLaunchKernelGGL((pwk_gemm_kernel<NG, true>), dim3((unsigned)(a.m_blocks * a.n_blocks)), dim3(256), 0, s, a, mode);
+    else hipLaunchKernelGGL((pwk_gemm_kernel<NG, false>), dim3((unsigned)(a.m_blocks * a.n_blocks)), dim3(256), 0, s, a, mode);
     return vip_launch_status("vip_conv2d_nhwc_f16(pwk)");
 }
 
@@ -659,8 +682,8 @@ int launch(const ConvArgs& a0, int groups, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, const void* residual,
-                                   void* y, const vip_conv_desc* d, void* stream) {
+static int conv2d_impl(const void* x, const void* gate, const void* w, const float* bias, const void* residual, void* y,
+                       const vip_conv_desc* d, void* stream) {
     VIP_REQUIRE(x && w && y && d, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_f16: null pointer");
     VIP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 &&
                     d->sh > 0 && d->sw > 0 && d->Ho > 0 && d->Wo > 0 && d->groups > 0 && d->pt >= 0 && d->pl >= 0,
@@ -700,6 +723,8 @@ extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bi
                 "vip_conv2d_nhwc_f16: input or weight tensor exceeds the 4 GiB buffer-addressing range");
     a.act_pre = d->act_pre; a.act_post = d->act_post;
     a.m_blocks = a.n_blocks = 0;
+    a.gate = (const f16*)gate;
+    a.gate_hw = d->Ho * d->Wo;
     hipStream_t s = (hipStream_t)stream;
     // HBM-bound shapes (short K): a smaller M tile -> 24-48 KB LDS and half the accumulators -> 3-5 workgroups per
     // CU in flight instead of 2, which is what hides the load -> MFMA -> store latency chain of a 1-4 k-tile block.
@@ -715,13 +740,29 @@ extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bi
         if (!residual && d->act_post == VIP_ACT_NONE) mode = d->act_pre;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_NONE) mode = 5;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_RELU) mode = 6;
-        if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536) return launch_pw_k<4>(a, mode, s);
+        if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) return launch_pw_k<4>(a, mode, s);
         if (mode >= 0 && (pw_mode & 2) && a.x_span_bytes < 0xFFFF0000L - 2L * a.K)
             // (a 64 x 256 wave tile at one wave per SIMD - NG = 4 - measured 15-40 % slower than NG = 2 at two)
             return cout_g <= 64 ? launch_pwk<1>(a, mode, s) : launch_pwk<2>(a, mode, s);
     }
+    VIP_REQUIRE(!gate, VIP_ERR_UNSUPPORTED,
+                "vip_conv2d_gated_nhwc_f16: only 1x1 stride-1 ungrouped convolutions with (activation) or (residual [+ReLU]) "
+                "epilogues take a gate; apply vip_scale_add_act_f16 first");
     if (cout_g <= 64) return short_k ? launch<64, 64>(a, d->groups, s) : launch<128, 64>(a, d->groups, s);
     return short_k ? launch<64, 128>(a, d->groups, s) : launch<128, 128>(a, d->groups, s);
+}
+
+extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                                   const vip_conv_desc* d, void* stream) {
+    return conv2d_impl(x, nullptr, w, bias, residual, y, d, stream);
+}
+
+extern "C" int vip_conv2d_gated_nhwc_f16(const void* x, const void* gate, const void* w, const float* bias,
+                                         const void* residual, void* y, const vip_conv_desc* d, void* stream) {
+    VIP_REQUIRE(gate, VIP_ERR_BAD_ARG, "vip_conv2d_gated_nhwc_f16: null gate");
+    VIP_REQUIRE(d && d->cin_off == 0 && d->ldx == d->Cin, VIP_ERR_UNSUPPORTED,
+                "vip_conv2d_gated_nhwc_f16: the gate indexes the whole input channel axis (cin_off = 0, ldx = Cin)");
+    return conv2d_impl(x, gate, w, bias, residual, y, d, stream);
 }
 
 extern "C" int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const void* residual,

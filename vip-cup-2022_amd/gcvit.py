@@ -78,8 +78,7 @@ class _ConvBranch:
         """returns x + branch(x)"""
         y = ops.dwconv2d(x, self.dw, None, 3, 1, PAD1, act="gelu")
         s = ops.se_gate(y, self.fc0, self.fc2, "gelu", "sigmoid")
-        y = ops.scale_add_act(y, s, None, None)
-        return ops.conv2d(y, self.pw, residual=x)
+        return ops.conv2d(y, self.pw, residual=x, gate=s)    # y * s folded into the 1x1 conv's activation load
 
 
 class _LN:

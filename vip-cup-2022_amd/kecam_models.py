@@ -283,10 +283,8 @@ class EfficientNet(_Base):
             else:
                 h = ops.conv2d(y, blk["exp"], act=act) if blk["exp"] is not None else y
                 h = ops.dwconv2d(h, blk["dw"][0], blk["dw"][1], k, s, self._pad(h.shape[1:3], k, s), act=act)
-                if blk["se"] is not None:
-                    a = ops.se_gate(h, blk["se"][0], blk["se"][1], act, "sigmoid")
-                    h = ops.scale_add_act(h, a, None, None)
-                y = ops.conv2d(h, blk["out"], residual=inp if blk["shortcut"] else None)
+                a = ops.se_gate(h, blk["se"][0], blk["se"][1], act, "sigmoid") if blk["se"] is not None else None
+                y = ops.conv2d(h, blk["out"], residual=inp if blk["shortcut"] else None, gate=a)   # h * se folded in
             last_of_stage = i + 1 == len(self.blocks) or self.blocks[i + 1]["stage"] != blk["stage"]
             if collect is not None and last_of_stage:
                 collect.append(y)

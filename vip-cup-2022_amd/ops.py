@@ -122,16 +122,37 @@ def make_dense_weight(kernel_io: torch.Tensor, bias: Optional[torch.Tensor], dev
     return make_conv_weight(kernel_io.reshape(1, 1, *kernel_io.shape), bias, 1, device, None, pad_cout_to)
 
 
+def gemm_kernel_name(M: int, K: int, kh: int, kw: int, sh: int, sw: int, pad, groups: int, same_size: bool,
+                     act, act_post, has_res: bool) -> str:
+    """Which kernel vip_conv2d_nhwc_f16 dispatches to (mirror of the selection at the end of csrc/conv_igemm.hip;
+    used only to label profiler records)."""
+    pointwise = (groups == 1 and kh == 1 and kw == 1 and sh == 1 and sw == 1 and not any(pad) and same_size)
+    epi_ok = ((not has_res and act_post is None) or (has_res and act is None and act_post in (None, "relu")))
+    if pointwise and epi_ok:
+        return "pw_gemm_kernel" if (K <= 256 and M >= 65536) else "pwk_gemm_kernel"
+    return "conv_igemm_kernel"
+
+
 def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None,
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           cin_off: int = 0, cout_off: int = 0) -> torch.Tensor:
-    """y = act_post(act(conv(x) + bias) + residual).  ``pad`` = (top, bottom, left, right) zero padding.
+           cin_off: int = 0, cout_off: int = 0, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act_post(act(conv(x * gate) + bias) + residual).  ``pad`` = (top, bottom, left, right) zero padding.
+    ``gate`` [B, Cin] fp16 (a squeeze-excite scale) is folded into the activation load of pointwise convolutions;
+    where the C ABI does not take it, x * gate is materialised first - the same fp16 values either way.
     ``x`` may carry more channels than the weight consumes (``cin_off`` selects the slice); ``out`` may
     be a wider tensor written at ``cout_off`` (concat-free channel splits / joins)."""
     _chk16(x, "conv2d.x")
     B, H, W, ldx = x.shape
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     pt, pb, pl, pr = pad
+    if gate is not None:
+        _chk16(gate, "conv2d.gate")
+        assert gate.shape == (B, cw.cin) and ldx == cw.cin and cin_off == 0
+        foldable = gemm_kernel_name(1 << 20, 1 << 20, cw.kh, cw.kw, sh, sw, pad, cw.groups,
+                                    True, act, act_post, residual is not None) != "conv_igemm_kernel"
+        if not foldable or B * H * W * ldx * 2 >= 0xFFFF0000 - 2 * ldx:
+            x = scale_add_act(x, gate, None, None)
+            gate = None
     Ho = (H + pt + pb - cw.kh) // sh + 1
     Wo = (W + pl + pr - cw.kw) // sw + 1
     if out is None:
@@ -150,9 +171,17 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
     if _PROF is not None:
         M = B * Ho * Wo
         kk = cw.kh * cw.kw * cw.alg_cin_g
-        tok = _PROF.start("conv_igemm_kernel", 2.0 * M * cw.cout * kk,
+        name = gemm_kernel_name(M, cw.kh * cw.kw * cw.cin_g, cw.kh, cw.kw, sh, sw, pad, cw.groups, (Ho, Wo) == (H, W),
+                                act, act_post, residual is not None)
+        if gate is not None:
+            name = "pwk_gemm_kernel"
+        tok = _PROF.start(name, 2.0 * M * cw.cout * kk,
                           2.0 * (B * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()))
-    st = _abi.lib().vip_conv2d_nhwc_f16(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), C.byref(d), _stream())
+    if gate is not None:
+        st = _abi.lib().vip_conv2d_gated_nhwc_f16(_p(x), _p(gate), _p(cw.w), _p(cw.bias), _p(residual), _p(out),
+                                                  C.byref(d), _stream())
+    else:
+        st = _abi.lib().vip_conv2d_nhwc_f16(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), C.byref(d), _stream())
     if tok is not None:
         _PROF.stop(tok)
     _abi.check(st, "vip_conv2d_nhwc_f16")
@@ -173,7 +202,8 @@ def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Op
         ldr = cw.cout
     tok = None
     if _PROF is not None:
-        tok = _PROF.start("conv_igemm_kernel", 2.0 * M * cw.cout * K,
+        name = gemm_kernel_name(M, K, 1, 1, 1, 1, (0, 0, 0, 0), 1, True, act, act_post, residual is not None)
+        tok = _PROF.start(name, 2.0 * M * cw.cout * K,
                           2.0 * (M * K + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()))
     st = _abi.lib().vip_gemm_bias_act_f16(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), M, cw.cout, K,
                                           K, cw.ldw, cw.cout, ldr, _act(act), _act(act_post), _stream())
@@ -200,7 +230,7 @@ def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual:
         g, b, eps = (ln[0], ln[1], float(ln[2])) if ln is not None else (None, None, 0.0)
         tok = None
         if _PROF is not None:
-            tok = _PROF.start("conv_igemm_kernel", 4.0 * M * C_ * hid,
+            tok = _PROF.start("mlp_fused_kernel" if C_ <= 96 else "mlp_stream_kernel", 4.0 * M * C_ * hid,
                               2.0 * (M * C_ * (3 if residual is not None else 2) + fc1.w.numel() + fc2.w.numel()))
         st = _abi.lib().vip_mlp_fused_f16(_p(x), _p(g), _p(b), eps, _p(fc1.w), _p(fc1.bias), _p(fc2.w), _p(fc2.bias),
                                           _p(residual), _p(out), M, C_, hid, C_, fc1.ldw, fc2.ldw, C_,

@@ -102,8 +102,7 @@ class Workload:
         tf = d["flops"] / sec / 1e12
         gbs = d["bytes"] / sec / 1e9
         intensity = d["flops"] / max(d["bytes"], 1.0)
-        label = {"conv_igemm_kernel": "conv/GEMM family: conv_igemm_kernel + pw_gemm_kernel + pwk_gemm_kernel"}.get(fam, fam)
-        common = {"kernel": label, "traffic": _pmc_traffic(fam), "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/)",
+        common = {"kernel": fam, "traffic": _pmc_traffic(fam), "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/)",
                   "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "launches": d["launches"],
                   "avg_launch_ms": d["ms"] / d["launches"]}
         if intensity * peak_gbs * 1e9 >= peak_tflops * 1e12:
@@ -126,9 +125,8 @@ def _pmc_traffic(fam: str):
     import json
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_hbm_traffic_pmc.json")
-    key = {"conv_igemm_kernel": "conv_gemm", "window_attn_kernel": "window_attn"}.get(fam)
     try:
-        return json.load(open(path))[key]["hbm_bytes_per_launch"]
+        return json.load(open(path))[fam]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
