@@ -485,8 +485,10 @@ int launch_pw_k(const ConvArgs& a, int mode, hipStream_t s) {
 // each wave owns 64 pixels and loads their activation fragments global -> VGPR one chunk ahead.  Against the
 // im2col tile kernel this halves LDS traffic (no activation round trip), removes the per-k-tile im2col address
 // arithmetic from the VALU (offsets here are linear in k) and gives each wave a 64 x 128 accumulator tile.
+// Short-K variant of the kernel below: the activation fragments are fetched global -> VGPR directly (no LDS image,
+// one barrier per chunk).  2-5 % faster than the LDS-staged form for K < 768, 5-10 % slower beyond (bench_gemm.py).
 template <int NG, bool GATED>
-__global__ __launch_bounds__(256, 2) void pwk_gemm_kernel(ConvArgs a, int mode) {
+__global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode) {
     constexpr int PT = 4, NB = 64 * NG, ROWB = 160;          // LDS row: 64 halfs + 32 B pad (stride = 32 mod 64: launch_pw)
     constexpr int STAGE = NB * ROWB;
     constexpr int W_IT = NB / 32;                            // 16-byte weight chunks staged per thread per k-chunk
@@ -652,13 +654,229 @@ __global__ __launch_bounds__(256, 2) void pwk_gemm_kernel(ConvArgs a, int mode) 
     }
 }
 
+
+template <int NG, bool GATED, int WN>
+__global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(ConvArgs a, int mode) {
+    // 4 x WN waves: wave (wm, wn) owns pixels 64 wm .. +63 and channels (64 NG) wn .. of the 256 x (64 NG WN) block tile.
+    // WN = 2 halves the L2 traffic of the activations (each activation image feeds two waves) at the same number of
+    // resident waves per CU (one 8-wave workgroup instead of two 4-wave ones).
+    constexpr int PT = 4, NB = 64 * NG, NBLK = NB * WN, ROWB = 160;   // LDS row: 64 halfs + 32 B pad (32 mod 64: launch_pw)
+    constexpr int NTHR = 256 * WN;
+    constexpr int STAGE = NBLK * ROWB;
+    constexpr int W_IT = NBLK * 8 / NTHR;                    // 16-byte weight chunks staged per thread per k-chunk (4)
+    constexpr int X_IT = 256 * 8 / NTHR;                     // 16-byte activation chunks per thread per k-chunk (8 / WN)
+    constexpr int XS = 64 * ROWB;                            // one activation image: 64 pixels x 64 k
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 weight stages][4 activation images]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mb = bid / a.n_blocks, nb = bid - mb * a.n_blocks;
+    const int mblk = mb * 256;                               // first pixel of the block tile
+    const int m0 = mblk + wm * 64;                           // first pixel of this wave
+    const int nblk = nb * NBLK;
+    const int n0 = nblk + wn * NB;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + a.cin_off), 0, (unsigned)min((long)0xFFFFFFF0L, a.x_span_bytes - 2L * a.cin_off), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_res =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (unsigned)a.res_span_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (unsigned)a.y_span_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_bias =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)(a.bias_elems * 4) : 0u, 0x00020000);
+
+    // weight staging: thread -> (LDS row j = tid/8 + (NTHR/8) i, 16-byte chunk c = tid%8); row j holds channel perm(j)
+    const int wc = tid & 7;
+    unsigned w_off[W_IT];
+    int w_lds[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int j = (tid >> 3) + (NTHR / 8) * i;
+        const int t = (j >> 4) & 3, r = j & 15;
+        const int ch = nblk + (j & ~63) + (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3);
+        w_off[i] = ch < a.Cout_g ? (unsigned)((ch * a.ldw + wc * 8) * 2) : OOB;
+        w_lds[i] = j * ROWB + wc * 16;
+    }
+    // Activation staging: the block's 256 pixels x 64 k of a chunk are fetched in FULL 128-byte lines (8 consecutive
+    // lanes = one pixel row's 64 halfs, 8 rows per wave-instruction), parked in four 64-pixel LDS images and read back
+    // as MFMA fragments.  Fetching the fragments directly (16 rows x 64 B per instruction) costs the texture path two
+    // half-used lines per row; and with the activation descriptor zero-sized (timing-only build) the K = 3072 GEMM ran
+    // 1.84x faster: the activation fetch, not the matrix core, sets this kernel's pace.
+    // WN = 1: every wave stages its OWN image (rows 64 wm + lane/8 + 8 i), so rewriting it needs no workgroup barrier -
+    // LDS executes one wave's accesses in order; WN = 2: the images are shared, all threads stage all of them.
+    constexpr int XROWS = WN == 1 ? 8 : NTHR / 8;            // rows covered by one staging pass of this thread's group
+    const int xr = WN == 1 ? wm * 64 + (lane >> 3) : (tid >> 3);
+    const int xc = tid & 7;                                  // 16-byte chunk
+    char* ximg = smem + 2 * STAGE;
+    const unsigned x_base = (unsigned)(((mblk + xr) * a.ldx + xc * 8) * 2);
+    const unsigned x_rstep = (unsigned)(XROWS * a.ldx * 2);
+    // squeeze-excite gate folded into the activation operand: x[m, k] * gate[image(m), k], the fp16 product rounded
+    // once - bit-identical to scale_add_act writing x * gate as fp16 and this kernel reading it back
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.gate, 0, GATED ? (unsigned)min((long)0xFFFFFFF0L, 2L * ((a.M + a.gate_hw - 1) / a.gate_hw) * a.K) : 0u, 0x00020000);
+    unsigned g_off[GATED ? X_IT : 1];
+    if constexpr (GATED) {
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+            const int m = mblk + xr + XROWS * i;
+            g_off[i] = m < a.M ? (unsigned)(((m / a.gate_hw) * a.K + xc * 8) * 2) : 0xFFFF0000u;
+        }
+    }
+    const int nk = (a.K + 63) >> 6;
+
+    uint4 wst[W_IT];
+    auto load_w = [&](int kc) {
+        const bool ok = kc * 64 + wc * 8 < a.K;
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i)
+            wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? w_off[i] + kc * 128 : OOB, 0, 0));
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + w_lds[i]) = wst[i];
+    };
+    U4H8 xst[X_IT], gst[GATED ? X_IT : 1];
+    auto load_x = [&](int kc) {
+        // weights of the K tail are zero in LDS, but 0 * (Inf/NaN garbage of the next row) is NaN: mask the lanes
+        const bool kok = kc * 64 + xc * 8 < a.K;
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+            const bool ok = kok & (mblk + xr + XROWS * i < a.M);
+            xst[i].u = __builtin_bit_cast(
+                uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_base + i * x_rstep + kc * 128 : OOB, 0, 0));
+        }
+        if constexpr (GATED) {
+#pragma unroll
+            for (int i = 0; i < X_IT; ++i)
+                gst[i].u = __builtin_bit_cast(
+                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, kok ? g_off[i] + kc * 128 : OOB, 0, 0));
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+            if constexpr (GATED) xst[i].h = xst[i].h * gst[i].h;                     // 4 x v_pk_mul_f16
+            *reinterpret_cast<uint4*>(ximg + (xr + XROWS * i) * ROWB + xc * 16) = xst[i].u;   // image r/64, row r%64
+        }
+    };
+    const char* xs = ximg + wm * XS;
+
+    f32x4 acc[NG][PT][4];
+    {   // bias is the C operand of the first MFMA of every accumulator
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + g * 64 + (nt >> 1) * 32 + lq * 8 + (nt & 1) * 4;
+                const f32x4 bv = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_bias, n < a.Cout_g ? (unsigned)(n * 4) : OOB, 0, 0));
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[g][p][nt] = bv;
+            }
+    }
+
+    load_w(0);
+    load_x(0);
+    store_w(0);
+    store_x();
+    __syncthreads();
+
+    auto compute = [&](int buf, int ks) {
+        const char* ws = smem + buf * STAGE + l15 * ROWB + lq * 16 + ks * 64;
+        const char* xl = xs + l15 * ROWB + lq * 16 + ks * 64;
+        U4H8 xf[PT];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) xf[p].u = *reinterpret_cast<const uint4*>(xl + p * 16 * ROWB);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            U4H8 wf[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + (g * 64 + nt * 16) * ROWB);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[p].h, acc[g][p][nt], 0, 0, 0);
+        }
+    };
+
+    // The next chunk's weights and activations are requested (global -> VGPR) before this chunk's math and written to
+    // LDS after it; the weight image is double-buffered, the activation images are single-buffered (LDS budget) and
+    // rewritten between two barriers.  Everything in the loop is
+    // unconditional (a chunk past the end is all out-of-range offsets: zeros, no memory traffic): a branch around a
+    // prefetch makes hipcc fold the "loads skipped" path into its vmcnt bookkeeping, and without the sched_barriers
+    // it sinks every load below the MFMAs, right in front of its wait - both silently serialise the pipeline.
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        load_w(kc + 1);
+        load_x(kc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(buf, 0);
+        compute(buf, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store_w(buf ^ 1);
+        if constexpr (WN > 1) __syncthreads();   // every wave is done reading the (single-buffered, shared) activation images
+        store_x();
+        __syncthreads();
+    }
+
+    // opaque to the optimiser: otherwise the epilogue's address arithmetic is hoisted above the k-loop and its
+    // ~20 registers stay live through it (the loop is at the 256-VGPR limit of two waves per SIMD)
+    int m_base = m0 + l15, n_lane = n0 + lq * 8;
+    asm volatile("" : "+v"(m_base), "+v"(n_lane));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int n_first = n_lane + g * 64;
+        switch (mode) {
+            case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+        }
+    }
+}
+
 template <int NG>
-int launch_pwk(const ConvArgs& a0, int mode, hipStream_t s) {
+int launch_pwk_direct(const ConvArgs& a0, int mode, hipStream_t s) {
     ConvArgs a = a0;
     a.m_blocks = (a.M + 255) / 256;
     a.n_blocks = (a.Cout_g + 64 * NG - 1) / (64 * NG);
-    if (a.gate) hipLaunchKernelGGL((pwk_gemm_kernel<NG, true>), dim3((unsigned)(a.m_blocks * a.n_blocks)), dim3(256), 0, s, a, mode);
-    else hipLaunchKernelGGL((pwk_gemm_kernel<NG, false>), dim3((unsigned)(a.m_blocks * a.n_blocks)), dim3(256), 0, s, a, mode);
+    const dim3 grid((unsigned)(a.m_blocks * a.n_blocks));
+    if (a.gate) hipLaunchKernelGGL((pwk_direct_kernel<NG, true>), grid, dim3(256), 0, s, a, mode);
+    else hipLaunchKernelGGL((pwk_direct_kernel<NG, false>), grid, dim3(256), 0, s, a, mode);
+    return vip_launch_status("vip_conv2d_nhwc_f16(pwk-direct)");
+}
+
+template <int NG, int WN>
+int launch_pwk(const ConvArgs& a0, int mode, hipStream_t s) {
+    ConvArgs a = a0;
+    a.m_blocks = (a.M + 255) / 256;
+    a.n_blocks = (a.Cout_g + 64 * NG * WN - 1) / (64 * NG * WN);
+    constexpr size_t smem = (2 * 64 * NG * WN + 4 * 64) * 160;     // 2 weight stages + 4 activation images
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, true, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, false, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(a.m_blocks * a.n_blocks));
+    if (a.gate) hipLaunchKernelGGL((pwk_gemm_kernel<NG, true, WN>), grid, dim3(256 * WN), smem, s, a, mode);
+    else hipLaunchKernelGGL((pwk_gemm_kernel<NG, false, WN>), grid, dim3(256 * WN), smem, s, a, mode);
     return vip_launch_status("vip_conv2d_nhwc_f16(pwk)");
 }
 
@@ -741,9 +959,17 @@ static int conv2d_impl(const void* x, const void* gate, const void* w, const flo
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_NONE) mode = 5;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_RELU) mode = 6;
         if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) return launch_pw_k<4>(a, mode, s);
-        if (mode >= 0 && (pw_mode & 2) && a.x_span_bytes < 0xFFFF0000L - 2L * a.K)
+        if (mode >= 0 && (pw_mode & 2) && a.x_span_bytes < 0xFFFFFFF0L) {
             // (a 64 x 256 wave tile at one wave per SIMD - NG = 4 - measured 15-40 % slower than NG = 2 at two)
-            return cout_g <= 64 ? launch_pwk<1>(a, mode, s) : launch_pwk<2>(a, mode, s);
+            static const int xl_min_k = getenv("VIP_PWK_XLK") ? atoi(getenv("VIP_PWK_XLK")) : 768;
+            if (a.K < xl_min_k && a.x_span_bytes < 0xFFFF0000L - 2L * a.K)
+                return cout_g <= 64 ? launch_pwk_direct<1>(a, mode, s) : launch_pwk_direct<2>(a, mode, s);
+            if (cout_g <= 64) return launch_pwk<1, 1>(a, mode, s);
+            // 256 x 256 block tiles (8 waves): 5 % on deep-K layers whose N is a multiple of 256; slower whenever the last
+            // 256-channel tile is half empty (N = 384: 258 -> 346 us) or K is short
+            if (cout_g % 256 == 0 && a.K >= 1024 && (long)((M + 255) / 256) * (cout_g / 256) >= 256) return launch_pwk<2, 2>(a, mode, s);
+            return launch_pwk<2, 1>(a, mode, s);
+        }
     }
     VIP_REQUIRE(!gate, VIP_ERR_UNSUPPORTED,
                 "vip_conv2d_gated_nhwc_f16: only 1x1 stride-1 ungrouped convolutions with (activation) or (residual [+ReLU]) "
