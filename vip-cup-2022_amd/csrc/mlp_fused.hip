@@ -473,7 +473,7 @@ int launch_mlp_stream(MlpArgs a, hipStream_t s) {
 
 extern "C" int vip_mlp_fused_supported(int M, int C, int hidden, int act) {
     if (act != VIP_ACT_GELU || hidden % 32 != 0 || hidden <= 0 || M < 8192) return 0;
-    if (C == 192) return 1;   // streamed weights (C = 128 is wired up too but measured slower than two GEMMs: not offered)
+    if (C == 192) return 1;   // streamed weights (C = 128 and 256 are wired up too but measured slower than two GEMMs)
     if (C != 64 && C != 96) return 0;
     const long s1 = mlp_stride(C / 8), s2 = mlp_stride(hidden >> 3);      // LDS-resident weights
     return (long)hidden * s1 + (long)C * s2 <= 160 * 1024;
@@ -507,6 +507,7 @@ extern "C" int vip_mlp_fused_f16(const void* x, const float* ln_gamma, const flo
     else if (C == 96) st = launch_mlp<3>(a, (hipStream_t)stream);
     else if (C == 128) st = launch_mlp_stream<4>(a, (hipStream_t)stream);
     else if (C == 192) st = launch_mlp_stream<6>(a, (hipStream_t)stream);
+    else if (C == 256) st = launch_mlp_stream<8>(a, (hipStream_t)stream);
     VIP_REQUIRE(st != 1, VIP_ERR_UNSUPPORTED, "vip_mlp_fused_f16: weights do not fit in LDS");
     return st;
 }
