@@ -40,6 +40,28 @@ def test_argument_checks_do_not_need_a_gpu():
     assert st == -1 and b"null" in lib.vip_last_error()
     st = lib.vip_layernorm_f16(C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), 4, 12, 1e-5, None)
     assert st == -2
+    p = C.c_void_p(16)
+    # fused MLP: shape support is a pure function; unsupported shapes / half-given LayerNorm are refused with a message
+    assert lib.vip_mlp_fused_supported(100000, 96, 384, 3) == 1 and lib.vip_mlp_fused_supported(100000, 192, 768, 3) == 1
+    assert lib.vip_mlp_fused_supported(100000, 96, 384, 2) == 0      # only GELU
+    assert lib.vip_mlp_fused_supported(100000, 384, 1536, 3) == 0    # weights do not fit / y accumulators too wide
+    assert lib.vip_mlp_fused_supported(100, 96, 384, 3) == 0         # too few tokens to fill the chip
+    st = lib.vip_mlp_fused_f16(p, None, None, 0.0, p, None, p, None, None, p, 100000, 384, 1536, 384, 384, 1536, 384, 0, 3, None)
+    assert st == -3 and b"unsupported" in lib.vip_last_error()
+    st = lib.vip_mlp_fused_f16(p, p, None, 1e-6, p, None, p, None, None, p, 100000, 96, 384, 96, 96, 384, 96, 0, 3, None)
+    assert st == -1 and b"ln_gamma" in lib.vip_last_error()
+    # SE gate: alignment and width limits
+    st = lib.vip_se_gate_f16(p, p, None, p, None, p, 4, 49, 100, 100, 8, 104, 100, 8, 2, 4, None)
+    assert st == -2
+    st = lib.vip_se_gate_f16(p, p, None, p, None, p, 4, 49, 32768, 32768, 8, 32768, 32768, 8, 2, 4, None)
+    assert st == -3 and b"too wide" in lib.vip_last_error()
+    # gated conv: only pointwise convolutions take a gate
+    d = _abi.ConvDesc(B=1, H=8, W=8, Cin=16, Cout=16, kh=3, kw=3, sh=1, sw=1, pt=1, pl=1, Ho=8, Wo=8, groups=1, ldx=16,
+                      cin_off=0, ldy=16, cout_off=0, ldr=0, res_off=0, ldw=144, act_pre=0, act_post=0)
+    st = lib.vip_conv2d_gated_nhwc_f16(p, p, p, None, None, p, C.byref(d), None)
+    assert st == -3 and b"gate" in lib.vip_last_error()
+    st = lib.vip_conv2d_gated_nhwc_f16(p, None, p, None, None, p, C.byref(d), None)
+    assert st == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -285,17 +285,32 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
             }
         }
 
-        // store: lane owns query qn, head-dim d = 16*dt + 4g + (0..3)
-        if (item_ok && qn < WS * WS) {
+        // store: lane owns query qn, head-dim d = 16*dt + 4g + (0..3).  Lane pairs (g, g^1) swap one 8-byte half so
+        // that every lane holds 8 CONSECUTIVE channels and the four lanes of a token write its whole 64-byte head
+        // slice with one 16-byte store each (two 8-byte stores per lane left 32-byte fragments in every line).
+        {
             const float inv = 1.f / lsum;
-            const long pix = img_pix + (long)(wy * WS + qy) * a.Wp + (wx * WS + qx);
-            f16* dst = a.out + pix * a.C + head * 32 + 4 * g;
+            union { f16x4 h; unsigned u[2]; } o0, o1, snd, rcv;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                f16x4 ov;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[dt][r] * inv);
-                *reinterpret_cast<f16x4*>(dst + 16 * dt) = ov;
+            for (int r = 0; r < 4; ++r) {
+                o0.h[r] = (f16)(o[0][r] * inv);
+                o1.h[r] = (f16)(o[1][r] * inv);
+            }
+            const bool odd = g & 1;
+            snd.u[0] = odd ? o0.u[0] : o1.u[0];
+            snd.u[1] = odd ? o0.u[1] : o1.u[1];
+            rcv.u[0] = __shfl_xor(snd.u[0], 16, 64);
+            rcv.u[1] = __shfl_xor(snd.u[1], 16, 64);
+            if (item_ok && qn < WS * WS) {
+                const long pix = img_pix + (long)(wy * WS + qy) * a.Wp + (wx * WS + qx);
+                // even g: channels 4g .. 4g+7 = own dt0 half + partner's dt0 half; odd g: 16+4(g-1) .. = partner's dt1 + own dt1
+                f16* dst = a.out + pix * a.C + head * 32 + (odd ? 16 + 4 * (g - 1) : 4 * g);
+                uint4 v;
+                v.x = odd ? rcv.u[0] : o0.u[0];
+                v.y = odd ? rcv.u[1] : o0.u[1];
+                v.z = odd ? o1.u[0] : rcv.u[0];
+                v.w = odd ? o1.u[1] : rcv.u[1];
+                *reinterpret_cast<uint4*>(dst) = v;
             }
         }
     }
