@@ -1,33 +1,40 @@
-"""Diagnostic (not a pytest file): separates the fp16-weight and fp16-activation contributions to the logit
-error of each member, on the CPU, with the calibrated heads."""
+"""Diagnostic (not a pytest file): separates the fp16-weight and fp16-activation contributions to the logit error
+of a member, on the CPU, with the calibrated heads.    python tests/diag_error_sources.py gcvit_tiny [n_images]
+
+  oracle          fp32 weights, fp32 activations  (oracle/*_ref.py)
+  emul w16        the product's host graph with its folded fp16 weights, fp32 activations  (tests/emul_ops.py)
+  emul w16+a16    the same with every operator output rounded to fp16 (what the kernels store)
+"""
 import importlib, io, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from PIL import Image
-import vipcup_amd
-from vipcup_amd import zoo
+import vipcup_amd  # noqa
+from vipcup_amd import zoo, gcvit, resnet_rs, tfimm_models as tm, kecam_models as km
 from oracle import ops_ref as R
 from tests import emul_ops
 from tools.make_synth import synth_jpeg
 
-members = sys.argv[1:] or zoo.ENSEMBLE
-idx = list(range(100, 108))
-pix = [np.asarray(Image.open(io.BytesIO(synth_jpeg(i))).convert("RGB")) for i in idx]
-for key in members:
-    spec = zoo.MEMBERS[key]
-    x = torch.stack([R.decode_resize_normalize(p, spec.input_hw, spec.input_hw) for p in pix]).half().float()
-    params = zoo.build_params(key)
-    ref = importlib.import_module(f"oracle.{spec.oracle}")
-    with torch.no_grad():
-        z = ref.predict_logits(key, params, x)[:, 0]
-        x8 = emul_ops.to_device_nhwc8(x)
-        with emul_ops.patched(round_act=False):
-            zw = spec.ctor({k: v for k, v in params.items()}).logits(x8)[:, 0] if False else None
-        res = {}
-        for ra in (False, True):
-            with emul_ops.patched(round_act=ra):
-                import inspect
-                kw = {"device": "cpu"}
-                m = spec.ctor.__call__(params) if False else None
-            res[ra] = None
-    print(key)
+key = sys.argv[1] if len(sys.argv) > 1 else "gcvit_tiny"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+spec = zoo.MEMBERS[key]
+pix = [np.asarray(Image.open(io.BytesIO(synth_jpeg(100 + i))).convert("RGB")) for i in range(n)]
+x = torch.stack([R.decode_resize_normalize(p, spec.input_hw, spec.input_hw) for p in pix]).half().float()
+params = zoo.build_params(key)
+ref = importlib.import_module(f"oracle.{spec.oracle}")
+CTORS = {"gcvit_tiny": lambda p: gcvit.GCViTTiny(p, device="cpu"),
+         "efficientnet_v1b4": lambda p: km.EfficientNet(p, "EfficientNetV1B4", device="cpu"),
+         "efficientnet_v2t": lambda p: km.EfficientNet(p, "EfficientNetV2T", device="cpu"),
+         "resnest50": lambda p: km.ResNest50(p, device="cpu") if hasattr(km, "ResNest50") else None}
+with torch.no_grad():
+    z = ref.predict_logits(key, params, x)[:, 0]
+    print("oracle       ", z.numpy().round(4))
+    x8 = emul_ops.to_device_nhwc8(x)
+    from vipcup_amd import ops
+    ops.KEEP_ROUNDING_ERROR = True
+    for ra, bc in ((False, False), (True, False), (False, True), (True, True)):
+        emul_ops.BIAS_CORRECT = bc
+        with emul_ops.patched(round_act=ra):
+            m = CTORS[key](params)
+            zz = m.logits(x8)[:, 0].float()
+        print(f"emul w16{'+a16' if ra else '    '}{' +bias-corr' if bc else '           '} ", zz.numpy().round(4), " dz", (zz - z).numpy().round(4))

@@ -10,6 +10,7 @@ import torch
 from oracle import ops_ref as R
 
 ROUND_ACT = False
+BIAS_CORRECT = False     # add (W32 - W16) . E[x] to every conv/dense output (what calibrated bias correction does)
 ACTN = {0: None, 1: "relu", 2: "silu", 3: "gelu", 4: "sigmoid", None: None}
 
 
@@ -26,9 +27,20 @@ def _w(cw):
     return cw.w.float()[:, :k].reshape(cw.cout, cw.kh, cw.kw, cw.cin_g).permute(1, 2, 3, 0)
 
 
-def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=None, out=None, cin_off=0, cout_off=0):
+def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=None, out=None, cin_off=0, cout_off=0,
+           gate=None):
     xx = x[..., cin_off:cin_off + cw.cin]
-    y = R.act(R.conv2d(xx, _w(cw), cw.bias, stride, pad, cw.groups), _an(act))
+    if gate is not None:
+        xx = _r(xx * gate[:, None, None, :])
+    y = R.conv2d(xx, _w(cw), cw.bias, stride, pad, cw.groups)
+    if BIAS_CORRECT and cw.err is not None:
+        mu = xx.reshape(-1, xx.shape[-1]).mean(0)                                  # [Cin]
+        k = cw.kh * cw.kw * cw.cin_g
+        e = cw.err[:, :k].reshape(cw.cout, cw.kh * cw.kw, cw.cin_g)
+        cog = cw.cout // cw.groups
+        corr = torch.stack([(e[o] * mu[(o // cog) * cw.cin_g:(o // cog + 1) * cw.cin_g]).sum() for o in range(cw.cout)])
+        y = y + corr
+    y = R.act(y, _an(act))
     if residual is not None:
         y = y + residual[..., :cw.cout]
     y = _r(R.act(y, _an(act_post)))
@@ -39,10 +51,23 @@ def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=
 
 
 def dense(x, cw, act=None, act_post=None, residual=None):
-    y = R.act(x @ _w(cw)[0, 0] + (cw.bias if cw.bias is not None else 0), _an(act))
+    y = x @ _w(cw)[0, 0] + (cw.bias if cw.bias is not None else 0)
+    if BIAS_CORRECT and cw.err is not None:
+        y = y + cw.err[:, :x.shape[-1]] @ x.reshape(-1, x.shape[-1]).mean(0)
+    y = R.act(y, _an(act))
     if residual is not None:
         y = y + residual
     return _r(R.act(y, _an(act_post)))
+
+
+def mlp(x, fc1, fc2, act="gelu", residual=None, ln=None):
+    if ln is not None:
+        x = layernorm(x, ln[0], ln[1], float(ln[2]))
+    return dense(dense(x, fc1, act=act), fc2, residual=residual)
+
+
+def se_gate(x, fc1, fc2, act1, act2="sigmoid"):
+    return dense(dense(global_avgpool(x), fc1, act=act1), fc2, act=act2)
 
 
 def dwconv2d(x, w_khwc, bias, k, stride=1, pad=(0, 0, 0, 0), act=None):
@@ -137,7 +162,7 @@ def patched(round_act=False):
     global ROUND_ACT
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops
-    names = ["conv2d", "dense", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
+    names = ["conv2d", "dense", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
              "scale_add_act", "radix_combine", "window_attention", "mhsa", "vit_tokens", "to_device_nhwc8"]
     saved = {n: getattr(ops, n) for n in names}
     old = ROUND_ACT

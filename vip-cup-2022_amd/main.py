@@ -77,7 +77,7 @@ def main(argv=None):
         assert [spec.input_hw, spec.input_hw] == list(dim), (name, dim)
         ckpts = sorted(glob(os.path.join(HERE, "ckpts", name, "ckpt", "*.npz")))
         if ckpts:
-            folds = [spec.ctor({k: torch.from_numpy(v) for k, v in np.load(c).items()}) for c in ckpts]
+            folds = [zoo.construct(spec, {k: torch.from_numpy(v) for k, v in np.load(c).items()}) for c in ckpts]
         elif a.synthetic:
             folds = [zoo.build_member(key)[1]]
         else:

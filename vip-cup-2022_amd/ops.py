@@ -55,6 +55,7 @@ class ConvWeight:
     cout: int
     groups: int = 1
     alg_cin_g: int = 0   # un-padded input channels per group (algorithmic FLOP count)
+    err: Optional[torch.Tensor] = None   # fp32 [cout, ldw]: (fp32 weight - stored fp16 weight), kept only until calibrate()
 
     @property
     def cin(self):
@@ -63,6 +64,43 @@ class ConvWeight:
     @property
     def ldw(self):
         return self.w.shape[1]
+
+
+KEEP_ROUNDING_ERROR = False   # set while a model is constructed for bias calibration: ConvWeight.err is populated
+_CALIB = False                # inside calibration(): conv/dense fold  (W32 - W16) . E[x]  into their bias, once
+
+
+class calibration:
+    """Context for ONE forward pass over a small representative batch that removes the image-independent part of the
+    fp16 weight-rounding error.  A layer computes W16 x instead of W32 x; the difference (W32 - W16) x has a data
+    mean (W32 - W16) E[x] that no rounding scheme can cancel when E[x_k] varies along K (LayerNorm beta/gamma, GELU /
+    swish outputs) - on GCViT-Tiny it is a constant +0.027 on the logit, 10x the image-dependent part.  Inside this
+    context every conv / dense measures its input's per-channel mean on the GPU, adds (W32 - W16) . mean to its fp32
+    bias and drops the error matrix; fused paths (MLP, SE gate) run unfused so that their inner layers are seen.
+    Standard post-training-quantisation bias correction; it needs inputs, not labels."""
+
+    def __enter__(self):
+        global _CALIB
+        self._old = _CALIB
+        _CALIB = True
+        return self
+
+    def __exit__(self, *exc):
+        global _CALIB
+        _CALIB = self._old
+        return False
+
+
+def _bias_correct(cw: "ConvWeight", x_eff: torch.Tensor):
+    """x_eff [..., cin] (already sliced / gated): fold (W32 - W16) . E[x] into cw.bias; E over all leading axes."""
+    mu = x_eff.reshape(-1, x_eff.shape[-1]).float().mean(0)                       # [cin]
+    k = cw.kh * cw.kw * cw.cin_g
+    cog = cw.cout // cw.groups
+    e = cw.err[:, :k].reshape(cw.groups, cog, cw.kh * cw.kw, cw.cin_g)
+    corr = (e * mu.reshape(cw.groups, 1, 1, cw.cin_g)).sum((2, 3)).reshape(cw.cout)
+    cw.bias = corr if cw.bias is None else (cw.bias + corr)
+    cw.bias = cw.bias.contiguous()
+    cw.err = None
 
 
 def diffuse_round_f16(w_rows: torch.Tensor) -> torch.Tensor:
@@ -111,9 +149,15 @@ def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], gr
     ldw = (ktot + 7) // 8 * 8
     if ldw != ktot:
         w = torch.cat([w, w.new_zeros(cout, ldw - ktot)], dim=1)
+    err = None
+    if KEEP_ROUNDING_ERROR:
+        w32 = k.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin_g)
+        if ldw != ktot:
+            w32 = torch.cat([w32, w32.new_zeros(cout, ldw - ktot)], dim=1)
+        err = (w32 - w.to(torch.float32)).to(device).contiguous()
     return ConvWeight(w=w.to(device=device, dtype=torch.float16).contiguous(),
                       bias=None if b is None else b.to(device).contiguous(),
-                      kh=kh, kw=kw, cin_g=cin_g, cout=cout, groups=groups, alg_cin_g=alg_cin_g)
+                      kh=kh, kw=kw, cin_g=cin_g, cout=cout, groups=groups, alg_cin_g=alg_cin_g, err=err)
 
 
 def make_dense_weight(kernel_io: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
@@ -150,9 +194,11 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
         assert gate.shape == (B, cw.cin) and ldx == cw.cin and cin_off == 0
         foldable = gemm_kernel_name(1 << 20, 1 << 20, cw.kh, cw.kw, sh, sw, pad, cw.groups,
                                     True, act, act_post, residual is not None) != "conv_igemm_kernel"
-        if not foldable or B * H * W * ldx * 2 >= 0xFFFF0000 - 2 * ldx:
+        if _CALIB or not foldable or B * H * W * ldx * 2 >= 0xFFFF0000 - 2 * ldx:
             x = scale_add_act(x, gate, None, None)
             gate = None
+    if _CALIB and cw.err is not None:
+        _bias_correct(cw, x[..., cin_off:cin_off + cw.cin])
     Ho = (H + pt + pb - cw.kh) // sh + 1
     Wo = (W + pl + pr - cw.kw) // sw + 1
     if out is None:
@@ -194,6 +240,8 @@ def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Op
     lead = x.shape[:-1]
     K = x.shape[-1]
     M = x.numel() // K
+    if _CALIB and cw.err is not None:
+        _bias_correct(cw, x)
     out = torch.empty((*lead, cw.cout), dtype=torch.float16, device=x.device)
     ldr = 0
     if residual is not None:
@@ -221,7 +269,7 @@ def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual:
     C_ = x.shape[-1]
     M = x.numel() // C_
     hid = fc1.cout
-    if (fc2.cout == C_ and fc1.groups == 1 and fc2.groups == 1 and x.is_contiguous()
+    if (not _CALIB and fc2.cout == C_ and fc1.groups == 1 and fc2.groups == 1 and x.is_contiguous()
             and _abi.lib().vip_mlp_fused_supported(M, C_, hid, _act(act))):
         out = torch.empty_like(x)
         if residual is not None:
@@ -254,7 +302,7 @@ def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmo
     B, H, W, Cc = x.shape
     assert fc1.groups == 1 and fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1
     assert fc1.cin == Cc and fc2.cin == fc1.cout, (fc1.cin, Cc, fc2.cin, fc1.cout)
-    if Cc * fc1.cout + fc1.cout * fc2.cout > 256 * 1024:
+    if _CALIB or Cc * fc1.cout + fc1.cout * fc2.cout > 256 * 1024:
         return dense(dense(global_avgpool(x), fc1, act=act1), fc2, act=act2)
     out = torch.empty((B, fc2.cout), dtype=torch.float16, device=x.device)
     st = _abi.lib().vip_se_gate_f16(_p(x), _p(fc1.w), _p(fc1.bias), _p(fc2.w), _p(fc2.bias), _p(out), B, H * W, Cc, Cc,

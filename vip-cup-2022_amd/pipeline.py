@@ -116,3 +116,16 @@ def build_dataset(paths: Sequence[str], batch_size: int, img_size: Tuple[int, in
             with open(p, "rb") as f:  # tf.io.read_file (:24)
                 raw.append(f.read())
         yield decode_jpegs(raw, device, threads).resized(img_size[0], img_size[1])
+
+
+def calibration_batch(n: int = 16, seed: int = 20221, device="cuda") -> DecodedBatch:
+    """A fixed, seeded batch of synthetic 200x200 RGB images (smooth colour field + pixel noise: the statistics of the
+    synthetic test set, SURVEY.md §8d, from a different seed) for ops.calibration().  With real checkpoints pass a
+    few real images through ``decode_jpegs`` instead - the correction only needs typical per-channel means."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.randn((n, 3, 8, 8), generator=g) * 48.0 + 128.0
+    field = torch.nn.functional.interpolate(low.clamp(0, 255), size=(200, 200), mode="bicubic", align_corners=False)
+    img = (field + torch.randn((n, 3, 200, 200), generator=g) * 12.0).clamp(0, 255).to(torch.uint8)
+    rgb = img.permute(0, 2, 3, 1).contiguous().to(device)
+    sizes = torch.tensor([[200, 200]] * n, dtype=torch.int32, device=device)
+    return DecodedBatch(rgb, sizes, [(200, 200)] * n)

@@ -87,9 +87,28 @@ def build_params(name: str, calibrated: bool = True):
     return params
 
 
-def build_member(name: str, calibrated: bool = True) -> Tuple[MemberSpec, object]:
+def construct(spec: MemberSpec, params, bias_calibration: bool = True):
+    """``spec.ctor(params)`` followed, on a GPU, by one calibration pass (ops.calibration: the image-independent part of
+    the fp16 weight-rounding error is folded into the fp32 biases).  ``bias_calibration=False`` gives the plain fp16
+    model."""
+    from . import ops, pipeline
+    if not (bias_calibration and torch.cuda.is_available()):
+        return spec.ctor(params)
+    ops.KEEP_ROUNDING_ERROR = True
+    try:
+        model = spec.ctor(params)
+    finally:
+        ops.KEEP_ROUNDING_ERROR = False
+    x = pipeline.calibration_batch().resized(spec.input_hw, spec.input_hw)
+    with ops.calibration():
+        model.logits(x)
+    torch.cuda.synchronize()
+    return model
+
+
+def build_member(name: str, calibrated: bool = True, bias_calibration: bool = True) -> Tuple[MemberSpec, object]:
     spec = MEMBERS[name]
-    return spec, spec.ctor(build_params(name, calibrated))
+    return spec, construct(spec, build_params(name, calibrated), bias_calibration)
 
 
 def by_ckpt_name(ckpt_name: str):
