@@ -38,3 +38,11 @@ with torch.no_grad():
             m = CTORS[key](params)
             zz = m.logits(x8)[:, 0].float()
         print(f"emul w16{'+a16' if ra else '    '}{' +bias-corr' if bc else '           '} ", zz.numpy().round(4), " dz", (zz - z).numpy().round(4))
+
+    if len(sys.argv) > 3:        # which operator's fp16 output rounding matters: skip one tag at a time
+        emul_ops.BIAS_CORRECT = True
+        for tag in sys.argv[3].split(","):
+            emul_ops.SKIP_ROUND = {tag}
+            with emul_ops.patched(round_act=True):
+                zz = CTORS[key](params).logits(x8)[:, 0].float()
+            print(f"a16 except {tag:9s}", (zz - z).numpy().round(4), " max|dz|", float((zz - z).abs().max()))

@@ -14,8 +14,11 @@ BIAS_CORRECT = False     # add (W32 - W16) . E[x] to every conv/dense output (wh
 ACTN = {0: None, 1: "relu", 2: "silu", 3: "gelu", 4: "sigmoid", None: None}
 
 
-def _r(t):
-    return t.to(torch.float16).to(torch.float32) if ROUND_ACT else t
+SKIP_ROUND = set()       # diagnostic: operator tags whose outputs are NOT rounded (conv, conv_res, dense, dw, saa, gap, gate_mul, ln, pool, attn)
+
+
+def _r(t, tag="other"):
+    return t.to(torch.float16).to(torch.float32) if (ROUND_ACT and tag not in SKIP_ROUND) else t
 
 
 def _an(a):
@@ -31,7 +34,7 @@ def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=
            gate=None):
     xx = x[..., cin_off:cin_off + cw.cin]
     if gate is not None:
-        xx = _r(xx * gate[:, None, None, :])
+        xx = _r(xx * gate[:, None, None, :], "gate_mul")
     y = R.conv2d(xx, _w(cw), cw.bias, stride, pad, cw.groups)
     if BIAS_CORRECT and cw.err is not None:
         mu = xx.reshape(-1, xx.shape[-1]).mean(0)                                  # [Cin]
@@ -43,7 +46,7 @@ def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=
     y = R.act(y, _an(act))
     if residual is not None:
         y = y + residual[..., :cw.cout]
-    y = _r(R.act(y, _an(act_post)))
+    y = _r(R.act(y, _an(act_post)), "conv_res" if residual is not None else "conv")
     if out is not None:
         out[..., cout_off:cout_off + cw.cout] = y
         return out
@@ -57,7 +60,7 @@ def dense(x, cw, act=None, act_post=None, residual=None):
     y = R.act(y, _an(act))
     if residual is not None:
         y = y + residual
-    return _r(R.act(y, _an(act_post)))
+    return _r(R.act(y, _an(act_post)), "dense")
 
 
 def mlp(x, fc1, fc2, act="gelu", residual=None, ln=None):
@@ -71,7 +74,7 @@ def se_gate(x, fc1, fc2, act1, act2="sigmoid"):
 
 
 def dwconv2d(x, w_khwc, bias, k, stride=1, pad=(0, 0, 0, 0), act=None):
-    return _r(R.act(R.dwconv2d(x, w_khwc.float()[..., None], bias, stride, pad), _an(act)))
+    return _r(R.act(R.dwconv2d(x, w_khwc.float()[..., None], bias, stride, pad), _an(act)), "dw")
 
 
 def layernorm(x, gamma, beta, eps):
@@ -94,7 +97,7 @@ def pool2d(x, k, stride, pad=(0, 0, 0, 0), mode=0):
 
 def global_avgpool(x):
     B, C = x.shape[0], x.shape[-1]
-    return _r(x.reshape(B, -1, C).mean(1))
+    return _r(x.reshape(B, -1, C).mean(1), "gap")
 
 
 def gap_dense_f32(x, w_nc, bias):
@@ -112,7 +115,7 @@ def scale_add_act(x, scale=None, residual=None, act=None):
         y = y * scale.reshape(scale.shape[0], *([1] * (x.dim() - 2)), scale.shape[-1])
     if residual is not None:
         y = y + residual
-    return _r(R.act(y, _an(act)))
+    return _r(R.act(y, _an(act)), "saa")
 
 
 def radix_combine(x, scale, radix=2):
