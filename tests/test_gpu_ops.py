@@ -136,6 +136,17 @@ def test_conv2d_gated(B, H, W, Cin, Cout, use_res, report):
     assert torch.equal(got, two), "gated conv differs from scale-then-conv"
 
 
+def test_conv2d_im2col_pointwise_kernel_all_cases():
+    """The im2col staging of the pointwise kernel is only dispatched for stems by default; VIP_PWK_CONV=1 routes every
+    eligible convolution through it (the switch is read once per process, hence the subprocess)."""
+    import os, subprocess, sys
+    env = dict(os.environ, VIP_PWK_CONV="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k",
+                        "test_conv2d and not im2col", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_conv2d_act_post_and_channel_slices(report):
     """act applied after the residual; input/outputs addressed as channel slices of wider tensors."""
     ops = _ops()

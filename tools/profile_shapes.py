@@ -15,10 +15,10 @@ torch.cuda.synchronize()
 rec = []
 orig_conv, orig_dense = ops.conv2d, ops.dense
 
-def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=None, out=None, cin_off=0, cout_off=0):
+def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=None, out=None, cin_off=0, cout_off=0, gate=None):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    y = orig_conv(x, cw, stride, pad, act, act_post, residual, out, cin_off, cout_off)
+    y = orig_conv(x, cw, stride, pad, act, act_post, residual, out, cin_off, cout_off, gate)
     e1.record()
     M = y.shape[0] * y.shape[1] * y.shape[2]
     rec.append((f"conv M={M} N={cw.cout} K={cw.kh*cw.kw*cw.cin_g} k{cw.kh} s{stride} g{cw.groups} Cin={cw.cin}", 2.0*M*cw.cout*cw.kh*cw.kw*cw.alg_cin_g,

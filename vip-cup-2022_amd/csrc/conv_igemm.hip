@@ -655,8 +655,21 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
 }
 
 
-template <int NG, bool GATED, int WN>
+template <int NG, bool GATED, int WN, bool IM2COL>
 __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(ConvArgs a, int mode) {
+    // IM2COL: the same kernel for k x k / strided / grouped convolutions - only the activation staging changes (each
+    // 16-byte chunk of a k-chunk belongs to one filter tap: the lane's tap and channel come from one division per
+    // chunk, the pixel coordinates of its rows are precomputed); group = blockIdx.y.
+    if constexpr (IM2COL) {
+        const int group = blockIdx.y;
+        a.x += group * a.Cin_g;
+        a.w += (size_t)group * a.Cout_g * a.ldw;
+        if (a.bias) a.bias += group * a.Cout_g;
+        a.bias_elems -= group * a.Cout_g;
+        a.cout_off += group * a.Cout_g;
+        a.res_off += group * a.Cout_g;
+        a.x_span_bytes -= 2L * group * a.Cin_g;
+    }
     // 4 x WN waves: wave (wm, wn) owns pixels 64 wm .. +63 and channels (64 NG) wn .. of the 256 x (64 NG WN) block tile.
     // WN = 2 halves the L2 traffic of the activations (each activation image feeds two waves) at the same number of
     // resident waves per CU (one 8-wave workgroup instead of two 4-wave ones).
@@ -720,6 +733,24 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
     char* ximg = smem + 2 * STAGE;
     const unsigned x_base = (unsigned)(((mblk + xr) * a.ldx + xc * 8) * 2);
     const unsigned x_rstep = (unsigned)(XROWS * a.ldx * 2);
+    int pix0[IM2COL ? X_IT : 1], hw0[IM2COL ? X_IT : 1];     // image base pixel, packed (hi0, wi0) of this lane's rows
+    if constexpr (IM2COL) {
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+            const int m = mblk + xr + XROWS * i;
+            int hi0 = -30000, wi0 = 0, pb = 0;
+            if (m < a.M) {
+                const int hw = a.Ho * a.Wo;
+                const int b = m / hw, rem = m - b * hw;
+                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                hi0 = ho * a.sh - a.pt;
+                wi0 = wo * a.sw - a.pl;
+                pb = b * a.H * a.W;
+            }
+            pix0[i] = pb;
+            hw0[i] = hi0 * 65536 + (wi0 & 0xFFFF);
+        }
+    }
     // squeeze-excite gate folded into the activation operand: x[m, k] * gate[image(m), k], the fp16 product rounded
     // once - bit-identical to scale_add_act writing x * gate as fp16 and this kernel reading it back
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
@@ -749,11 +780,24 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
     auto load_x = [&](int kc) {
         // weights of the K tail are zero in LDS, but 0 * (Inf/NaN garbage of the next row) is NaN: mask the lanes
         const bool kok = kc * 64 + xc * 8 < a.K;
+        if constexpr (IM2COL) {
+            const int k0 = kc * 64 + xc * 8;
+            const int tap = k0 / a.Cin_g, c = k0 - tap * a.Cin_g;
+            const int tr = tap / a.kw, ts = tap - tr * a.kw;
 #pragma unroll
-        for (int i = 0; i < X_IT; ++i) {
-            const bool ok = kok & (mblk + xr + XROWS * i < a.M);
-            xst[i].u = __builtin_bit_cast(
-                uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_base + i * x_rstep + kc * 128 : OOB, 0, 0));
+            for (int i = 0; i < X_IT; ++i) {
+                const int hi = (hw0[i] >> 16) + tr, wi = (int)(short)(hw0[i] & 0xFFFF) + ts;
+                const bool ok = kok & ((unsigned)hi < (unsigned)a.H) & ((unsigned)wi < (unsigned)a.W);
+                const unsigned off = (unsigned)(((pix0[i] + hi * a.W + wi) * a.ldx + c) * 2);
+                xst[i].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : OOB, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < X_IT; ++i) {
+                const bool ok = kok & (mblk + xr + XROWS * i < a.M);
+                xst[i].u = __builtin_bit_cast(
+                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_base + i * x_rstep + kc * 128 : OOB, 0, 0));
+            }
         }
         if constexpr (GATED) {
 #pragma unroll
@@ -868,16 +912,33 @@ int launch_pwk(const ConvArgs& a0, int mode, hipStream_t s) {
     constexpr size_t smem = (2 * 64 * NG * WN + 4 * 64) * 160;     // 2 weight stages + 4 activation images
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, true, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, true, WN, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, false, WN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, false, WN, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     const dim3 grid((unsigned)(a.m_blocks * a.n_blocks));
-    if (a.gate) hipLaunchKernelGGL((pwk_gemm_kernel<NG, true, WN>), grid, dim3(256 * WN), smem, s, a, mode);
-    else hipLaunchKernelGGL((pwk_gemm_kernel<NG, false, WN>), grid, dim3(256 * WN), smem, s, a, mode);
+    if (a.gate) hipLaunchKernelGGL((pwk_gemm_kernel<NG, true, WN, false>), grid, dim3(256 * WN), smem, s, a, mode);
+    else hipLaunchKernelGGL((pwk_gemm_kernel<NG, false, WN, false>), grid, dim3(256 * WN), smem, s, a, mode);
     return vip_launch_status("vip_conv2d_nhwc_f16(pwk)");
+}
+
+template <int NG>
+int launch_pwk_conv(const ConvArgs& a0, int mode, int groups, hipStream_t s) {
+    ConvArgs a = a0;
+    a.m_blocks = (a.M + 255) / 256;
+    a.n_blocks = (a.Cout_g + 64 * NG - 1) / (64 * NG);
+    constexpr size_t smem = (2 * 64 * NG + 4 * 64) * 160;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, false, 1, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(a.m_blocks * a.n_blocks), (unsigned)groups);
+    hipLaunchKernelGGL((pwk_gemm_kernel<NG, false, 1, true>), grid, dim3(256), smem, s, a, mode);
+    return vip_launch_status("vip_conv2d_nhwc_f16(pwk-im2col)");
 }
 
 template <int BM, int BN>
@@ -970,6 +1031,18 @@ static int conv2d_impl(const void* x, const void* gate, const void* w, const flo
             if (cout_g % 256 == 0 && a.K >= 1024 && (long)((M + 255) / 256) * (cout_g / 256) >= 256) return launch_pwk<2, 2>(a, mode, s);
             return launch_pwk<2, 1>(a, mode, s);
         }
+    }
+    {   // Stems (Cin <= 16: K = 72 / 128, a handful of taps per 64-k chunk) run on the pointwise kernel with im2col staging:
+        // 277 vs 385 us on the EfficientNet stems.  For wider convolutions the two kernels trade places shape by shape
+        // (total 35.9 vs 36.1 ms over the ensemble's launches), so those stay on the tile kernel.
+        int mode = -1;
+        if (!residual && d->act_post == VIP_ACT_NONE) mode = d->act_pre;
+        else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_NONE) mode = 5;
+        else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_RELU) mode = 6;
+        static const int im2col_all = getenv("VIP_PWK_CONV") ? atoi(getenv("VIP_PWK_CONV")) : 0;   // 1: every eligible conv (tests)
+        if ((cin_g <= 16 || im2col_all) && mode >= 0 && !gate && a.x_span_bytes < 0xFFFFFFF0L && d->H < 30000 &&
+            d->W < 30000 && d->pt < 16 && d->pl < 16)
+            return cout_g <= 64 ? launch_pwk_conv<1>(a, mode, d->groups, s) : launch_pwk_conv<2>(a, mode, d->groups, s);
     }
     VIP_REQUIRE(!gate, VIP_ERR_UNSUPPORTED,
                 "vip_conv2d_gated_nhwc_f16: only 1x1 stride-1 ungrouped convolutions with (activation) or (residual [+ReLU]) "
