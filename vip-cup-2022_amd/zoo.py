@@ -92,6 +92,8 @@ def construct(spec: MemberSpec, params, bias_calibration: bool = True):
     the fp16 weight-rounding error is folded into the fp32 biases).  ``bias_calibration=False`` gives the plain fp16
     model."""
     from . import ops, pipeline
+    if os.environ.get("VIP_BIAS_CALIBRATION", "1") == "0":     # profiling runs: keep the calibration launches out of the trace
+        bias_calibration = False
     if not (bias_calibration and torch.cuda.is_available()):
         return spec.ctor(params)
     ops.KEEP_ROUNDING_ERROR = True
