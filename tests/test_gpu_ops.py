@@ -178,6 +178,21 @@ def test_dense(M, K, N, report):
     check(report, f"dense {M}x{K}x{N}", got, ref)
 
 
+# at most 256 rows (squeeze-excite / ECA layers, M = batch): the barrier-free rows kernel; ragged M, N, K tails
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "silu", None])
+@pytest.mark.parametrize("M,K,N", [(256, 2048, 512), (256, 72, 1632), (200, 1536, 1536), (16, 1248, 56), (1, 64, 8), (256, 40, 104)])
+def test_dense_few_rows(M, K, N, act, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 3 + K + N)
+    x = h(torch.randn(M, K, generator=g))
+    w = h(torch.randn(K, N, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    ref = R.act(R.dense(x, w, b), act)
+    got = ops.dense(dev(x), ops.make_dense_weight(w, b), act=act)
+    torch.cuda.synchronize()
+    check(report, f"dense few-rows {act} {M}x{K}x{N}", got, ref)
+
+
 # epilogue variants of the pointwise kernels (activation only / residual / residual + post-ReLU) over the general-K
 # kernel's edge cases: K tail (K % 64 != 0), odd chunk counts, N <= 64 and N not a multiple of 64/128, M tail
 @pytest.mark.parametrize("mode", ["gelu", "silu", "relu", "sigmoid", "none", "res", "res_relu"])

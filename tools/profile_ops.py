@@ -13,7 +13,7 @@ for _ in range(2):
     wl.step(serial=True)
 torch.cuda.synchronize()
 rec = []
-NAMES = ["conv2d", "dense", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "scale_add_act",
+NAMES = ["conv2d", "dense", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "scale_add_act",
          "window_attention", "mhsa", "vit_tokens", "cls_dense_f32", "radix_combine"]
 
 

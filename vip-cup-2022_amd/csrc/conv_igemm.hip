@@ -941,6 +941,89 @@ int launch_pwk_conv(const ConvArgs& a0, int mode, int groups, hipStream_t s) {
     return vip_launch_status("vip_conv2d_nhwc_f16(pwk-im2col)");
 }
 
+// ---- Dense / 1x1 layers with at most 256 rows (the squeeze-excite and ECA layers: M = batch) ------------------------
+// On the tile kernels such a layer is ONE m-block: 2..16 workgroups walk K chunk by chunk behind a barrier each, 30-100
+// us of pure latency while the chip idles.  Here a workgroup owns 16 output channels for all rows, both MFMA operands
+// are loaded global -> VGPR directly (no LDS staging, no barrier in the loop), K is split over the workgroup's four
+// waves whose partial sums meet in LDS once, and (N/16) x (M/64) workgroups run side by side.
+__global__ __launch_bounds__(256) void rows_gemm_kernel(ConvArgs a) {
+    // workgroup = (16 channels, 64 rows): blockIdx.y = row quarter; its 4 waves split K and meet in LDS.  (One workgroup
+    // per channel slab streaming ALL rows was bound by a single CU's L2 bandwidth: 1 MB of activations per workgroup.)
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    __shared__ float red[3][1][16][64];                      // [kq-1][.][acc register][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mw = 0, kq = wave;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * 64;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + a.cin_off), 0, (unsigned)min((long)0xFFFFFFF0L, a.x_span_bytes - 2L * a.cin_off), 0x00020000);
+    const unsigned w_off = (n0 + l15 < a.Cout_g) ? (unsigned)(((n0 + l15) * a.ldw + lq * 8) * 2) : 0xFFFF0000u;
+    unsigned x_off[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = m0 + p * 16 + l15;
+        x_off[p] = m < a.M ? (unsigned)((m * a.ldx + lq * 8) * 2) : 0xFFFF0000u;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nks = (a.K + 31) >> 5;
+    const int per = ((nks + 3) / 4 + 3) & ~3;                // k-steps per K quarter, multiple of the unroll
+    const int ks_lo = kq * per, ks_hi = min(nks, ks_lo + per);
+    if (m0 < a.M) {
+        for (int ks0 = ks_lo; ks0 < ks_hi; ks0 += 4) {
+            U4H8 wf[4], xf[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = (ks0 + u < ks_hi) & ((ks0 + u) * 32 + lq * 8 < a.K);
+                wf[u].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? w_off + (ks0 + u) * 64 : OOB, 0, 0));
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    xf[u][p].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + (ks0 + u) * 64 : OOB, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u].h, xf[u][p].h, acc[p], 0, 0, 0);
+        }
+    }
+    if (kq > 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[kq - 1][mw][p * 4 + r][lane] = acc[p][r];
+    }
+    __syncthreads();
+    if (kq > 0 || m0 >= a.M) return;
+    // lane: row m0 + 16 p + l15, channels n0 + 4 lq + (0..3)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = m0 + p * 16 + l15;
+        if (m >= a.M) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + lq * 4 + r;
+            v[r] = acc[p][r] + red[0][mw][p * 4 + r][lane] + red[1][mw][p * 4 + r][lane] + red[2][mw][p * 4 + r][lane] +
+                   ((a.bias && n < a.Cout_g) ? a.bias[n] : 0.f);
+        }
+        f16* dst = a.y + (long)m * a.ldy + a.cout_off + n0 + lq * 4;
+        if (n0 + lq * 4 + 3 < a.Cout_g) {
+            f16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (f16)vip_act(v[r], a.act_pre);
+            *reinterpret_cast<f16x4*>(dst) = o;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + lq * 4 + r < a.Cout_g) dst[r] = (f16)vip_act(v[r], a.act_pre);
+        }
+    }
+}
+
 template <int BM, int BN>
 int launch(const ConvArgs& a0, int groups, hipStream_t s) {
     ConvArgs a = a0;
@@ -1019,6 +1102,11 @@ static int conv2d_impl(const void* x, const void* gate, const void* w, const flo
         if (!residual && d->act_post == VIP_ACT_NONE) mode = d->act_pre;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_NONE) mode = 5;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_RELU) mode = 6;
+        if (M <= 256 && !residual && !gate && d->act_post == VIP_ACT_NONE && d->ldy % 4 == 0 && d->cout_off % 4 == 0 &&
+            a.x_span_bytes < 0xFFFF0000L - 2L * a.K && 2L * cout_g * d->ldw < 0xFFFF0000L - 2L * a.K) {
+            hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)((cout_g + 15) / 16), (unsigned)((M + 63) / 64)), dim3(256), 0, s, a);
+            return vip_launch_status("vip_conv2d_nhwc_f16(rows)");
+        }
         if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) return launch_pw_k<4>(a, mode, s);
         if (mode >= 0 && (pw_mode & 2) && a.x_span_bytes < 0xFFFFFFF0L) {
             // (a 64 x 256 wave tile at one wave per SIMD - NG = 4 - measured 15-40 % slower than NG = 2 at two)
