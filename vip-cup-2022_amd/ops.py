@@ -172,6 +172,8 @@ def gemm_kernel_name(M: int, K: int, kh: int, kw: int, sh: int, sw: int, pad, gr
     used only to label profiler records)."""
     pointwise = (groups == 1 and kh == 1 and kw == 1 and sh == 1 and sw == 1 and not any(pad) and same_size)
     epi_ok = ((not has_res and act_post is None) or (has_res and act is None and act_post in (None, "relu")))
+    if pointwise and M <= 256 and not has_res and act_post is None:
+        return "rows_gemm_kernel"
     if pointwise and epi_ok:
         return "pw_gemm_kernel" if (K <= 256 and M >= 65536) else "pwk_gemm_kernel"
     return "conv_igemm_kernel"
