@@ -168,6 +168,10 @@ int vip_gap_dense_f32(const void* x, const float* W, const float* bias, float* o
  * scale [B,C] f16 or NULL (=1); residual f16 or NULL. */
 int vip_scale_add_act_f16(const void* x, const void* scale, const void* residual, void* y,
                           int B, int HW, int C, int act, void* stream);
+/* Same with a second output  y2 = act2(y)  computed from the fp16-rounded y (bit-identical to a second launch reading y
+ * back): NormFreeNet's block needs both x_{l+1} and act(x_{l+1}) (kecam nfnets.py:116-168).  y2 may be NULL. */
+int vip_scale_add_act2_f16(const void* x, const void* scale, const void* residual, void* y, void* y2,
+                           int B, int HW, int C, int act, int act2, void* stream);
 
 /* ResNeSt split-attention combine (kecam resnest/resnest.py:57-61): out[b,p,c] = sum_r x[b,p,r*C+c] *
  * scale[b,r*C+c].  x f16 [B,HW,radix*C]; scale f16 [B,radix*C] (the r-softmax weights); out [B,HW,C]. */

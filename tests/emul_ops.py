@@ -109,7 +109,10 @@ def cls_dense_f32(t, w_nc, bias):
     return t[:, 0] @ w_nc.t() + (bias if bias is not None else 0)
 
 
-def scale_add_act(x, scale=None, residual=None, act=None):
+def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
+    if act2 is not None:
+        y = scale_add_act(x, scale, residual, act)
+        return y, _r(R.act(y, _an(act2)), "saa")
     y = x
     if scale is not None:
         y = y * scale.reshape(scale.shape[0], *([1] * (x.dim() - 2)), scale.shape[-1])

@@ -326,6 +326,19 @@ def test_pools(report):
     check(report, "global_avgpool", got, R.global_avgpool(x))
 
 
+def test_scale_add_act_two_outputs(report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    x = dev(torch.randn(3, 9, 9, 64, generator=g))
+    sc = dev(torch.rand(3, 64, generator=g))
+    res = dev(torch.randn(3, 9, 9, 64, generator=g))
+    y, y2 = ops.scale_add_act(x, sc, res, None, act2="silu")
+    y_ref = ops.scale_add_act(x, sc, res, None)
+    y2_ref = ops.scale_add_act(y_ref, None, None, "silu")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and torch.equal(y2, y2_ref)
+
+
 def test_scale_add_act_and_head(report):
     ops = _ops()
     g = torch.Generator().manual_seed(4)

@@ -51,6 +51,7 @@ SIGNATURES = {
     "vip_global_avgpool_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_gap_dense_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vip_scale_add_act_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vip_scale_add_act2_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vip_radix_combine_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_window_attn_fwd_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _vp]),
     "vip_mhsa_fwd_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void gap_kernel(const f16* __restrict__ x, f16
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void scale_add_act_kernel(const f16* __restrict__ x, const f16* __restrict__ sc,
                                                             const f16* __restrict__ res, f16* __restrict__ y,
-                                                            long total8, int HW, int C8, int act) {
+                                                            f16* __restrict__ y2, long total8, int HW, int C8, int act,
+                                                            int act2) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (long)gridDim.x * 256) {
         const int c8 = (int)(idx % C8);
         const long pix = idx / C8;
@@ -116,6 +117,12 @@ __global__ __launch_bounds__(256) void scale_add_act_kernel(const f16* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.e[j] = (f16)vip_act(f[j], act);
         *reinterpret_cast<uint4*>(y + idx * 8) = o.u;
+        if (y2) {   // second output act2(y) from the ROUNDED y: what a separate launch reading y back would compute
+            U4H8 o2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o2.e[j] = (f16)vip_act((float)o.e[j], act2);
+            *reinterpret_cast<uint4*>(y2 + idx * 8) = o2.u;
+        }
     }
 }
 
@@ -270,15 +277,21 @@ extern "C" int vip_global_avgpool_f16(const void* x, void* y, int B, int HW, int
     return vip_launch_status("vip_global_avgpool_f16");
 }
 
-extern "C" int vip_scale_add_act_f16(const void* x, const void* scale, const void* residual, void* y, int B, int HW,
-                                     int C, int act, void* stream) {
+extern "C" int vip_scale_add_act2_f16(const void* x, const void* scale, const void* residual, void* y, void* y2, int B,
+                                      int HW, int C, int act, int act2, void* stream) {
     VIP_REQUIRE(x && y, VIP_ERR_BAD_ARG, "vip_scale_add_act_f16: null pointer");
-    VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && (unsigned)act <= 4u, VIP_ERR_BAD_ARG, "vip_scale_add_act_f16: bad argument");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && (unsigned)act <= 4u && (unsigned)act2 <= 4u, VIP_ERR_BAD_ARG,
+                "vip_scale_add_act_f16: bad argument");
     VIP_REQUIRE(C % 8 == 0, VIP_ERR_ALIGNMENT, "vip_scale_add_act_f16: C must be a multiple of 8");
     const long total8 = (long)B * HW * (C / 8);
-    hipLaunchKernelGGL(scale_add_act_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)x, (const f16*)scale, (const f16*)residual, (f16*)y, total8, HW, C / 8, act);
+    hipLaunchKernelGGL(scale_add_act_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
+                       (const f16*)scale, (const f16*)residual, (f16*)y, (f16*)y2, total8, HW, C / 8, act, act2);
     return vip_launch_status("vip_scale_add_act_f16");
+}
+
+extern "C" int vip_scale_add_act_f16(const void* x, const void* scale, const void* residual, void* y, int B, int HW,
+                                     int C, int act, void* stream) {
+    return vip_scale_add_act2_f16(x, scale, residual, y, nullptr, B, HW, C, act, VIP_ACT_NONE, stream);
 }
 
 extern "C" int vip_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int rows, int C,

@@ -398,9 +398,9 @@ class NormFreeNet(_Base):
         y = ops.conv2d(y, self.stem[1], pad=PAD1, act=act)
         y = ops.conv2d(y, self.stem[2], pad=PAD1, act=act)
         y = ops.conv2d(y, self.stem[3], stride=2, pad=PAD1)
-        for blk in self.blocks:                                                # block (:116-168)
+        pre = ops.scale_add_act(y, None, None, act)                            # act(x); beta folded into the convs
+        for bi, blk in enumerate(self.blocks):                                 # block (:116-168)
             s = blk["stride"]
-            pre = ops.scale_add_act(y, None, None, act)                        # act(x); beta folded into the convs
             if blk["sc"] is not None:
                 H, W = pre.shape[1], pre.shape[2]
                 sc = ops.pool2d(pre, 2, 2, (0, H % 2, 0, W % 2), ops.POOL_AVG_VALID) if s > 1 else pre
@@ -412,7 +412,10 @@ class NormFreeNet(_Base):
             d = ops.conv2d(d, blk["d3"], pad=PAD1, act=act)
             d = ops.conv2d(d, blk["d4"])
             a = ops.dense(ops.global_avgpool(d), blk["eca"], act="sigmoid")
-            y = ops.scale_add_act(d, a, sc, None)
+            if bi + 1 < len(self.blocks):      # the next block's act(x) is a second output of this launch
+                y, pre = ops.scale_add_act(d, a, sc, None, act2=act)
+            else:
+                y = ops.scale_add_act(d, a, sc, None)
             if collect is not None and blk["last"]:
                 collect.append(y)
         return ops.conv2d(y, self.post, act=act)

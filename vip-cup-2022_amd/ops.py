@@ -378,8 +378,8 @@ def gap_dense_f32(x, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     return out
 
 
-def scale_add_act(x, scale=None, residual=None, act=None):
-    """act(x * scale[b,c] + residual)"""
+def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
+    """act(x * scale[b,c] + residual); with ``act2`` returns ``(y, act2(y))`` from one launch."""
     _chk16(x, "scale_add_act.x")
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
@@ -390,9 +390,11 @@ def scale_add_act(x, scale=None, residual=None, act=None):
         _chk16(residual, "scale_add_act.residual")
         assert residual.shape == x.shape
     out = torch.empty_like(x)
-    st = _abi.lib().vip_scale_add_act_f16(_p(x), _p(scale), _p(residual), _p(out), B, HW, Cc, _act(act), _stream())
-    _abi.check(st, "vip_scale_add_act_f16")
-    return out
+    out2 = torch.empty_like(x) if act2 is not None else None
+    st = _abi.lib().vip_scale_add_act2_f16(_p(x), _p(scale), _p(residual), _p(out), _p(out2), B, HW, Cc, _act(act),
+                                           _act(act2), _stream())
+    _abi.check(st, "vip_scale_add_act2_f16")
+    return out if act2 is None else (out, out2)
 
 
 def window_attention(qkv, q_global, bias_table, heads: int, ws: int, scale: float):
