@@ -167,7 +167,7 @@ def make_dense_weight(kernel_io: torch.Tensor, bias: Optional[torch.Tensor], dev
 
 
 def gemm_kernel_name(M: int, K: int, kh: int, kw: int, sh: int, sw: int, pad, groups: int, same_size: bool,
-                     act, act_post, has_res: bool) -> str:
+                     act, act_post, has_res: bool, cin_g: int = 1 << 20) -> str:
     """Which kernel vip_conv2d_nhwc_f16 dispatches to (mirror of the selection at the end of csrc/conv_igemm.hip;
     used only to label profiler records)."""
     pointwise = (groups == 1 and kh == 1 and kw == 1 and sh == 1 and sw == 1 and not any(pad) and same_size)
@@ -176,6 +176,8 @@ def gemm_kernel_name(M: int, K: int, kh: int, kw: int, sh: int, sw: int, pad, gr
         return "rows_gemm_kernel"
     if pointwise and epi_ok:
         return "pw_gemm_kernel" if (K <= 256 and M >= 65536) else "pwk_gemm_kernel"
+    if epi_ok and cin_g <= 16:
+        return "pwk_gemm_kernel"          # stems: im2col staging on the pointwise kernel
     return "conv_igemm_kernel"
 
 
@@ -220,7 +222,7 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
         M = B * Ho * Wo
         kk = cw.kh * cw.kw * cw.alg_cin_g
         name = gemm_kernel_name(M, cw.kh * cw.kw * cw.cin_g, cw.kh, cw.kw, sh, sw, pad, cw.groups, (Ho, Wo) == (H, W),
-                                act, act_post, residual is not None)
+                                act, act_post, residual is not None, cw.cin_g)
         if gate is not None:
             name = "pwk_gemm_kernel"
         tok = _PROF.start(name, 2.0 * M * cw.cout * kk,
