@@ -8,10 +8,10 @@ from oracle import gcvit_ref as ref  # noqa: E402
 from tests.test_gpu_resnet_rs import _images  # noqa: E402
 
 
-def _run(cfg, n, report, tag, seed=1002):
+def _run(cfg, n, report, tag, seed=1002, size=224):
     import vipcup_amd  # noqa: F401
     from vipcup_amd import gcvit, ops
-    x = _images(n, 224).to(torch.float16).to(torch.float32)
+    x = _images(n, size).to(torch.float16).to(torch.float32)
     p = gcvit.synth_params(cfg, seed=seed)
     ca, cb = [], []
     with torch.no_grad():
@@ -43,5 +43,14 @@ def test_gcvit_shallow(report):
 
 def test_gcvit_tiny_full(report):
     frms, ze, z_ref = _run(ref.NAME2CONFIG["gcvit_tiny"], 4, report, "tiny")
+    assert frms < 5e-3
+    assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())
+
+
+def test_gcvit_fit_window_padding(report):
+    """200x200 input: the level feature maps (50, 25, 13, 7) are not multiples of the windows (7, 7, 14, 7), so
+    FitWindow pads them (feature.py:240-249) and the level crops back (level.py:61)."""
+    cfg = dict(ref.NAME2CONFIG["gcvit_tiny"], depths=(2, 2, 2, 2))
+    frms, ze, z_ref = _run(cfg, 2, report, "d2222@200", size=200)
     assert frms < 5e-3
     assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())

@@ -156,9 +156,11 @@ class GCViT:
         """GCViTLevel.call (level.py:46-67)"""
         ws = lv["ws"]
         B, H, W, C = x.shape
-        if H % ws or W % ws:
-            # FitWindow (feature.py:240-249) pads both sides; level.py:61 crops [:H,:W] afterwards
-            raise NotImplementedError("GCViT feature map not a multiple of the window: FitWindow padding not built yet")
+        ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+        if ph or pw:
+            # FitWindow (feature.py:240-249): zero-pad BOTH sides to a multiple of the window, the odd pixel after.
+            # NHWC: F.pad pairs run from the last axis backwards -> (C, C, W-left, W-right, H-top, H-bottom).
+            x = torch.nn.functional.pad(x, (0, 0, pw // 2, pw // 2 + pw % 2, ph // 2, ph // 2 + ph % 2)).contiguous()
         qg = x
         for branch, keep_dim in lv["qgen"]:
             qg = branch(qg)
@@ -167,6 +169,8 @@ class GCViT:
         qg = qg.reshape(B, ws * ws, C)
         for blk in lv["blocks"]:
             x = blk(x, qg)
+        if ph or pw:
+            x = x[:, :H, :W, :].contiguous()      # level.py:61 crops from the top-left corner (sic), as the reference does
         if lv["down"] is not None:
             x = lv["down"](x)
         return x
