@@ -223,10 +223,10 @@ typedef struct vip_jpeg_desc {
  * coefficients the image needs. */
 int vip_jpeg_probe_h(const uint8_t* jpeg_h, size_t len, vip_jpeg_desc* desc_h, size_t* coef_elems_h);
 
-/* Host, multithreaded: baseline-sequential Huffman decode (ITU-T T.81 Annex F) of n JPEG byte streams into
+/* Host, multithreaded: Huffman decode - sequential (ITU-T T.81 Annex F) and progressive (Annex G) - of n JPEG byte streams into
  * quantised DCT coefficients (natural order, int16, block-major per component) packed back to back in
  * coef_h; desc_h[i].coef_off are offsets into coef_h.  Replaces the entropy-decoding half of
- * tf.image.decode_jpeg (dataset/dataset.py:28).  Progressive / arithmetic / 12-bit / CMYK -> VIP_ERR_JPEG. */
+ * tf.image.decode_jpeg (dataset/dataset.py:28).  Arithmetic / lossless / 12-bit / CMYK -> VIP_ERR_JPEG. */
 int vip_jpeg_entropy_decode_h(const uint8_t* const* jpeg_h, const size_t* len_h, int n,
                               vip_jpeg_desc* desc_h, int16_t* coef_h, size_t coef_cap,
                               size_t* coef_used_h, int threads);

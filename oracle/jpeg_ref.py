@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE — pure Python / NumPy restatement of the JPEG decode that
-``tf.image.decode_jpeg(channels=3)`` (dataset/dataset.py:28) performs, i.e. of libjpeg-turbo's baseline
-path: Huffman entropy decoding (ITU-T T.81 Annex F / jdhuff.c), dequantisation + ``jpeg_idct_islow``
+``tf.image.decode_jpeg(channels=3)`` (dataset/dataset.py:28) performs, i.e. of libjpeg-turbo's Huffman
+paths: baseline / sequential entropy decoding (ITU-T T.81 Annex F / jdhuff.c), progressive entropy decoding (T.81
+Annex G / jdphuff.c: spectral selection + successive approximation over several scans), dequantisation + ``jpeg_idct_islow``
 (jidctint.c), ``h2v1/h2v2/h1v2_fancy_upsample`` (jdsample.c) and ``ycc_rgb_convert`` (jdcolor.c).
 
 The algorithm lives in a third-party dependency that is NOT vendored in the reference (TensorFlow bundles
@@ -94,7 +95,8 @@ def parse(data: bytes):
             break
         ln = (d[pos] << 8) | d[pos + 1]
         s = d[pos + 2:pos + ln]
-        if m in (0xC0, 0xC1):
+        if m in (0xC0, 0xC1, 0xC2):
+            P["progressive"] = (m == 0xC2)
             assert s[0] == 8
             P["h"], P["w"], nc = (s[1] << 8) | s[2], (s[3] << 8) | s[4], s[5]
             P["comp"] = [dict(id=s[6 + 3 * i], h=s[7 + 3 * i] >> 4, v=s[7 + 3 * i] & 15, tq=s[8 + 3 * i]) for i in range(nc)]
@@ -125,18 +127,155 @@ def parse(data: bytes):
             P["ri"] = (s[0] << 8) | s[1]
         elif m == 0xDA:
             ns = s[0]
+            idx = []
             for i in range(ns):
-                for c in P["comp"]:
+                for ci, c in enumerate(P["comp"]):
                     if c["id"] == s[1 + 2 * i]:
                         c["td"], c["ta"] = s[2 + 2 * i] >> 4, s[2 + 2 * i] & 15
+                        idx.append(ci)
             P["scan"] = d[pos + ln:]
-            return P
+            if not P.get("progressive") and ns == len(P["comp"]):
+                return P                                  # the single interleaved scan of a sequential file
+            # progressive (or multi-scan sequential): remember the scan with the tables in force, then skip its data
+            ss, se, ah, al = s[1 + 2 * ns], s[2 + 2 * ns], s[3 + 2 * ns] >> 4, s[3 + 2 * ns] & 15
+            P.setdefault("scans", []).append(dict(
+                comps=idx, td=[P["comp"][i]["td"] for i in idx], ta=[P["comp"][i]["ta"] for i in idx], ss=ss, se=se, ah=ah,
+                al=al, data=d[pos + ln:], dc=dict(P["dc"]), ac=dict(P["ac"]), ri=P["ri"]))
+            pos += ln
+            while pos + 1 < len(d) and not (d[pos] == 0xFF and d[pos + 1] != 0 and not 0xD0 <= d[pos + 1] <= 0xD7):
+                pos += 1
+            continue
         pos += ln
+    if P.get("scans"):
+        return P
     raise ValueError("no SOS")
+
+
+def _entropy_decode_scans(P):
+    """Progressive (and multi-scan sequential) entropy decoding: T.81 Annex G as libjpeg's jdphuff.c implements it.
+    Every scan refines the same coefficient arrays; non-interleaved scans walk ceil(component_size / 8) blocks."""
+    comps = P["comp"]
+    hmax = max(c["h"] for c in comps)
+    vmax = max(c["v"] for c in comps)
+    mx = -(-P["w"] // (8 * hmax))
+    my = -(-P["h"] // (8 * vmax))
+    coefs = [np.zeros((my * c["v"], mx * c["h"], 64), np.int64) for c in comps]
+    for sc in P["scans"]:
+        br = _Bits(sc["data"])
+        ss, se, ah, al = sc["ss"], sc["se"], sc["ah"], sc["al"]
+        state = dict(eobrun=0, pred=[0] * len(comps))
+
+        def block(ci, k_td, k_ta, blk):
+            if ss == 0 and not P.get("progressive"):          # sequential scan: a whole block
+                s_ = _sym(br, sc["dc"][k_td])
+                state["pred"][ci] += _extend(br.get(s_), s_)
+                blk[0] = state["pred"][ci]
+                k = 1
+                while k < 64:
+                    rs = _sym(br, sc["ac"][k_ta])
+                    r, sz = rs >> 4, rs & 15
+                    if sz == 0:
+                        if r != 15:
+                            break
+                        k += 16
+                        continue
+                    k += r
+                    blk[ZIGZAG[k]] = _extend(br.get(sz), sz)
+                    k += 1
+                return
+            if ss == 0:                                       # DC scan
+                if ah == 0:
+                    s_ = _sym(br, sc["dc"][k_td])
+                    state["pred"][ci] += _extend(br.get(s_), s_)
+                    blk[0] = state["pred"][ci] * (1 << al)
+                elif br.get(1):
+                    blk[0] |= 1 << al
+                return
+            if ah == 0:                                       # AC first pass (decode_mcu_AC_first)
+                if state["eobrun"] > 0:
+                    state["eobrun"] -= 1
+                    return
+                k = ss
+                while k <= se:
+                    rs = _sym(br, sc["ac"][k_ta])
+                    r, sz = rs >> 4, rs & 15
+                    if sz:
+                        k += r
+                        blk[ZIGZAG[k]] = _extend(br.get(sz), sz) * (1 << al)
+                    elif r == 15:
+                        k += 15
+                    else:
+                        state["eobrun"] = (1 << r) + (br.get(r) if r else 0) - 1
+                        break
+                    k += 1
+                return
+            p1, m1 = 1 << al, -(1 << al)                      # AC refinement (decode_mcu_AC_refine)
+
+            def refine(pos):
+                if blk[pos] != 0 and br.get(1) and (blk[pos] & p1) == 0:
+                    blk[pos] += p1 if blk[pos] >= 0 else m1
+
+            k = ss
+            if state["eobrun"] == 0:
+                while k <= se:
+                    rs = _sym(br, sc["ac"][k_ta])
+                    r, sz = rs >> 4, rs & 15
+                    val = 0
+                    if sz:
+                        val = p1 if br.get(1) else m1
+                    elif r != 15:
+                        state["eobrun"] = (1 << r) + (br.get(r) if r else 0)
+                        break
+                    while k <= se:
+                        pos = ZIGZAG[k]
+                        if blk[pos] != 0:
+                            refine(pos)
+                        else:
+                            r -= 1
+                            if r < 0:
+                                break
+                        k += 1
+                    if val:
+                        blk[ZIGZAG[k]] = val
+                    k += 1
+            if state["eobrun"] > 0:
+                while k <= se:
+                    refine(ZIGZAG[k])
+                    k += 1
+                state["eobrun"] -= 1
+
+        left = sc["ri"]
+        if len(sc["comps"]) > 1:                              # interleaved: MCU order
+            units = [(y, x) for y in range(my) for x in range(mx)]
+        else:                                                 # one component: its own block raster
+            c = comps[sc["comps"][0]]
+            bw = -(-(-(-P["w"] * c["h"] // hmax)) // 8)
+            bh = -(-(-(-P["h"] * c["v"] // vmax)) // 8)
+            units = [(y, x) for y in range(bh) for x in range(bw)]
+        for (y, x) in units:
+            if sc["ri"] and left == 0:
+                br.restart()
+                state["pred"] = [0] * len(comps)
+                state["eobrun"] = 0
+                left = sc["ri"]
+            if len(sc["comps"]) > 1:
+                for j, ci in enumerate(sc["comps"]):
+                    c = comps[ci]
+                    for by in range(c["v"]):
+                        for bx in range(c["h"]):
+                            block(ci, sc["td"][j], sc["ta"][j], coefs[ci][y * c["v"] + by, x * c["h"] + bx])
+            else:
+                ci = sc["comps"][0]
+                block(ci, sc["td"][0], sc["ta"][0], coefs[ci][y, x])
+            if sc["ri"]:
+                left -= 1
+    return coefs, (hmax, vmax)
 
 
 def entropy_decode(P):
     """-> list of int64 coefficient arrays [blocks_h, blocks_w, 64] (natural order, quantised)"""
+    if P.get("scans"):
+        return _entropy_decode_scans(P)
     comps = P["comp"]
     hmax = max(c["h"] for c in comps)
     vmax = max(c["v"] for c in comps)

@@ -36,6 +36,31 @@ def _variants():
     return out
 
 
+def _progressive():
+    """progressive (SOF2) encodings: libjpeg's default scan script has DC first/refine, AC first/refine scans,
+    interleaved DC scans and per-component AC scans"""
+    px = synth_pixels(5)
+    out = {}
+    for name, kw in {"p420": dict(quality=80, subsampling=2), "p444_q92": dict(quality=92, subsampling=0),
+                     "p422_q60": dict(quality=60, subsampling=1), "p420_q20": dict(quality=20, subsampling=2)}.items():
+        b = io.BytesIO()
+        Image.fromarray(px).save(b, format="JPEG", progressive=True, **kw)
+        out[name] = b.getvalue()
+    b = io.BytesIO()
+    Image.fromarray(px[:173, :131]).save(b, format="JPEG", quality=75, subsampling=2, progressive=True)
+    out["p_odd_173x131"] = b.getvalue()
+    b = io.BytesIO()
+    Image.fromarray(px).convert("L").save(b, format="JPEG", quality=80, progressive=True)
+    out["p_gray"] = b.getvalue()
+    b = io.BytesIO()
+    Image.fromarray(px[:90, :200]).save(b, format="JPEG", quality=75, subsampling=2, progressive=True,
+                                        restart_marker_blocks=2)
+    out["p_restart"] = b.getvalue()
+    for name, raw in out.items():
+        assert b"\xff\xc2" in raw, name
+    return out
+
+
 def _pil(b):
     return np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))
 
@@ -60,10 +85,15 @@ def test_oracle_matches_pillow_on_synthetic_set():
         assert np.array_equal(jpeg_ref.decode_rgb(raw), _pil(raw)), name
 
 
+def test_oracle_matches_pillow_on_progressive_streams():
+    for name, raw in _progressive().items():
+        assert np.array_equal(jpeg_ref.decode_rgb(raw), _pil(raw)), name
+
+
 def test_host_entropy_decoder_matches_oracle():
     import vipcup_amd  # noqa: F401
     from vipcup_amd import pipeline
-    raws = [synth_jpeg(i) for i in (0, 1, 49)] + list(_variants().values())
+    raws = [synth_jpeg(i) for i in (0, 1, 49)] + list(_variants().values()) + list(_progressive().values())
     raws.append(open(os.path.join(GOLD, "ref_cat.jpg"), "rb").read())
     desc, coef = pipeline.entropy_decode(raws, threads=3)
     for i, raw in enumerate(raws):
@@ -82,9 +112,10 @@ def test_host_entropy_decoder_matches_oracle():
 def test_unsupported_streams_are_rejected():
     import vipcup_amd  # noqa: F401
     from vipcup_amd import _abi, pipeline
-    b = io.BytesIO()
-    Image.fromarray(synth_pixels(3)).save(b, format="JPEG", quality=80, progressive=True)
+    raw = bytearray(synth_jpeg(3))
+    i = raw.find(b"\xff\xc0")
+    raw[i + 1] = 0xC9                                     # arithmetic-coded frame: not a Huffman stream
     with pytest.raises(_abi.VipError):
-        pipeline.entropy_decode([b.getvalue()])
+        pipeline.entropy_decode([bytes(raw)])
     with pytest.raises(_abi.VipError):
         pipeline.entropy_decode([b"not a jpeg at all"])

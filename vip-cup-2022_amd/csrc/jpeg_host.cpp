@@ -1,12 +1,12 @@
-// Host half of the JPEG path: marker parsing + baseline-sequential Huffman entropy decoding into
-// quantised DCT coefficients (ITU-T T.81 Annex F, the algorithm of libjpeg's jdhuff.c, which is what
-// tf.image.decode_jpeg — dataset/dataset.py:28 — runs first).  Dequantisation, IDCT, upsampling and colour
-// conversion happen on the GPU (jpeg_pipeline.hip).
+// Host half of the JPEG path: marker parsing + Huffman entropy decoding into quantised DCT coefficients - baseline /
+// sequential (ITU-T T.81 Annex F, libjpeg's jdhuff.c) and progressive (Annex G, jdphuff.c: spectral selection and
+// successive approximation over several scans, EOB runs, correction bits) - which is what tf.image.decode_jpeg
+// (dataset/dataset.py:28) runs first.  Dequantisation, IDCT, upsampling and colour conversion happen on the GPU
+// (jpeg_pipeline.hip); a progressive file ends in the same coefficient arrays as a sequential one.
 //
-// Scope: 8-bit baseline / extended-sequential Huffman (SOF0, SOF1), 1 or 3 components, sampling factors
-// h,v in {1,2} with the luma plane at the maximum, restart intervals, multiple scans NOT supported
-// (progressive SOF2, arithmetic SOF9+, lossless, 12-bit, CMYK -> VIP_ERR_JPEG; the reference has no
-// fallback either: TF raises).
+// Scope: 8-bit Huffman frames SOF0 / SOF1 / SOF2, 1 or 3 components, sampling factors h,v in {1,2} with the luma plane
+// at the maximum, restart intervals, any number of scans (arithmetic SOF9+, lossless, 12-bit, CMYK -> VIP_ERR_JPEG;
+// the reference has no fallback either: TF raises).
 #include <stdint.h>
 #include <string.h>
 
@@ -61,7 +61,17 @@ struct Component {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
 };
 
+struct Scan {
+    int ns = 0, comp[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int ss = 0, se = 63, ah = 0, al = 0, restart_interval = 0;
+    const uint8_t* data = nullptr;
+    size_t len = 0;
+    HuffTable dc[4], ac[4];   // the tables in force when the scan starts (DHT may be re-sent between scans)
+};
+
 struct Parsed {
+    bool progressive = false;
+    std::vector<Scan> scans;  // filled for progressive and multi-scan sequential files
     int width = 0, height = 0, ncomp = 0;
     Component comp[3];
     uint16_t qt[4][64];  // natural order
@@ -101,7 +111,8 @@ int parse(const uint8_t* d, size_t n, Parsed& P, bool need_scan) {
         }
         const uint8_t* s = d + pos + 2;
         const int sl = len - 2;
-        if (m == 0xC0 || m == 0xC1) {
+        if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+            P.progressive = (m == 0xC2);
             if (sl < 6 || s[0] != 8) {
                 vip_set_error("jpeg: only 8-bit precision is supported");
                 return VIP_ERR_JPEG;
@@ -137,8 +148,8 @@ int parse(const uint8_t* d, size_t n, Parsed& P, bool need_scan) {
             P.mcus_x = (P.width + 8 * P.hmax - 1) / (8 * P.hmax);
             P.mcus_y = (P.height + 8 * P.vmax - 1) / (8 * P.vmax);
             have_sof = true;
-        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            vip_set_error("jpeg: SOF%d (progressive / arithmetic / lossless) is not supported", m - 0xC0);
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            vip_set_error("jpeg: SOF%d (arithmetic / lossless / hierarchical) is not supported", m - 0xC0);
             return VIP_ERR_JPEG;
         } else if (m == 0xDB) {
             int o = 0;
@@ -189,10 +200,12 @@ int parse(const uint8_t* d, size_t n, Parsed& P, bool need_scan) {
                 return VIP_ERR_JPEG;
             }
             const int ns = s[0];
-            if (ns != P.ncomp || sl < 1 + 2 * ns + 3) {
-                vip_set_error("jpeg: multi-scan (non-interleaved) files are not supported");
+            if (ns < 1 || ns > P.ncomp || sl < 1 + 2 * ns + 3) {
+                vip_set_error("jpeg: bad SOS header");
                 return VIP_ERR_JPEG;
             }
+            Scan sc;
+            sc.ns = ns;
             for (int i = 0; i < ns; ++i) {
                 const int cid = s[1 + 2 * i];
                 bool found = false;
@@ -200,6 +213,9 @@ int parse(const uint8_t* d, size_t n, Parsed& P, bool need_scan) {
                     if (P.comp[c].id == cid) {
                         P.comp[c].td = s[2 + 2 * i] >> 4;
                         P.comp[c].ta = s[2 + 2 * i] & 15;
+                        sc.comp[i] = c;
+                        sc.td[i] = P.comp[c].td & 3;
+                        sc.ta[i] = P.comp[c].ta & 3;
                         found = true;
                     }
                 if (!found) {
@@ -209,14 +225,39 @@ int parse(const uint8_t* d, size_t n, Parsed& P, bool need_scan) {
             }
             P.scan = d + pos + len;
             P.scan_len = n - (pos + len);
-            return VIP_OK;
+            if (!P.progressive && ns == P.ncomp) return VIP_OK;      // the single interleaved scan of a sequential file
+            if (!need_scan) return VIP_OK;                           // probe: the frame header is all that is needed
+            sc.ss = s[1 + 2 * ns];
+            sc.se = s[2 + 2 * ns];
+            sc.ah = s[3 + 2 * ns] >> 4;
+            sc.al = s[3 + 2 * ns] & 15;
+            if (!P.progressive) { sc.ss = 0; sc.se = 63; sc.ah = sc.al = 0; }
+            if (sc.ss > sc.se || sc.se > 63 || sc.al > 13 || (sc.ss == 0 && sc.se != 0 && P.progressive) ||
+                (sc.ss > 0 && ns != 1)) {
+                vip_set_error("jpeg: bad progressive scan parameters (Ss=%d Se=%d Ah=%d Al=%d Ns=%d)", sc.ss, sc.se, sc.ah, sc.al, ns);
+                return VIP_ERR_JPEG;
+            }
+            sc.restart_interval = P.restart_interval;
+            sc.data = d + pos + len;
+            for (int t = 0; t < 4; ++t) {
+                sc.dc[t] = P.dc[t];
+                sc.ac[t] = P.ac[t];
+            }
+            // skip the entropy-coded segment: up to the next marker that is neither a stuffed 0xFF00 nor RSTn
+            size_t q = pos + len;
+            while (q + 1 < n && !(d[q] == 0xFF && d[q + 1] != 0x00 && !(d[q + 1] >= 0xD0 && d[q + 1] <= 0xD7))) ++q;
+            sc.len = q - (pos + len);
+            P.scans.push_back(sc);
+            pos = q;
+            continue;
         }
         pos += len;
     }
     if (!have_sof) {
-        vip_set_error("jpeg: no SOF0/SOF1 frame header");
+        vip_set_error("jpeg: no SOF0/SOF1/SOF2 frame header");
         return VIP_ERR_JPEG;
     }
+    if (!P.scans.empty()) return VIP_OK;
     if (need_scan) {
         vip_set_error("jpeg: no SOS");
         return VIP_ERR_JPEG;
@@ -300,7 +341,201 @@ inline int decode_sym(BitReader& br, const HuffTable& t) {
     }
 }
 
+// Progressive (and multi-scan sequential) decoding: every scan refines the same coefficient arrays.
+// Follows jdphuff.c (decode_mcu_DC_first / DC_refine / AC_first / AC_refine).
+int decode_scans(const Parsed& P, const vip_jpeg_desc& D, int16_t* coef) {
+    for (const Scan& sc : P.scans) {
+        for (int i = 0; i < sc.ns; ++i) {
+            const bool need_dc = sc.ss == 0 && sc.ah == 0, need_ac = sc.se > 0;
+            if ((need_dc && !sc.dc[sc.td[i]].present) || (need_ac && !sc.ac[sc.ta[i]].present)) {
+                vip_set_error("jpeg: scan uses a Huffman table that was not defined");
+                return VIP_ERR_JPEG;
+            }
+        }
+        BitReader br;
+        br.p = sc.data;
+        br.end = sc.data + sc.len;
+        int pred[3] = {0, 0, 0};
+        int eobrun = 0;
+        const int ss = sc.ss, se = sc.se, al = sc.al;
+        const int p1 = 1 << al, m1 = -(1 << al);
+        const bool sequential = !P.progressive;
+
+        auto block = [&](int i, int16_t* blk) -> int {
+            const int c = sc.comp[i];
+            const HuffTable& tdc = sc.dc[sc.td[i]];
+            const HuffTable& tac = sc.ac[sc.ta[i]];
+            if (sequential) {
+                br.refill();
+                const int s = decode_sym(br, tdc);
+                if (s < 0 || s > 11) return -1;
+                br.refill();
+                pred[c] += extend(br.get(s), s);
+                blk[0] = (int16_t)pred[c];
+                for (int k = 1; k < 64;) {
+                    br.refill();
+                    const int rs = decode_sym(br, tac);
+                    if (rs < 0) return -1;
+                    const int r = rs >> 4, sz = rs & 15;
+                    if (sz == 0) {
+                        if (r != 15) break;
+                        k += 16;
+                        continue;
+                    }
+                    k += r;
+                    if (k > 63) return -1;
+                    blk[ZIGZAG[k]] = (int16_t)extend(br.get(sz), sz);
+                    ++k;
+                }
+                return 0;
+            }
+            if (ss == 0) {                                   // DC scan
+                br.refill();
+                if (sc.ah == 0) {
+                    const int s = decode_sym(br, tdc);
+                    if (s < 0 || s > 11) return -1;
+                    br.refill();
+                    pred[c] += extend(br.get(s), s);
+                    blk[0] = (int16_t)(pred[c] * (1 << al));
+                } else if (br.get(1)) {
+                    blk[0] |= (int16_t)p1;
+                }
+                return 0;
+            }
+            if (sc.ah == 0) {                                // AC first pass
+                if (eobrun > 0) {
+                    --eobrun;
+                    return 0;
+                }
+                for (int k = ss; k <= se; ++k) {
+                    br.refill();
+                    const int rs = decode_sym(br, tac);
+                    if (rs < 0) return -1;
+                    const int r = rs >> 4, sz = rs & 15;
+                    if (sz) {
+                        k += r;
+                        if (k > 63) return -1;
+                        br.refill();
+                        blk[ZIGZAG[k]] = (int16_t)(extend(br.get(sz), sz) * (1 << al));
+                    } else if (r == 15) {
+                        k += 15;
+                    } else {
+                        eobrun = 1 << r;
+                        if (r) {
+                            br.refill();
+                            eobrun += br.get(r);
+                        }
+                        --eobrun;
+                        break;
+                    }
+                }
+                return 0;
+            }
+            // AC refinement
+            auto refine = [&](int pos) {
+                if (blk[pos] != 0) {
+                    br.refill();
+                    if (br.get(1) && (blk[pos] & p1) == 0) blk[pos] = (int16_t)(blk[pos] + (blk[pos] >= 0 ? p1 : m1));
+                }
+            };
+            int k = ss;
+            if (eobrun == 0) {
+                for (; k <= se; ++k) {
+                    br.refill();
+                    const int rs = decode_sym(br, tac);
+                    if (rs < 0) return -1;
+                    int r = rs >> 4;
+                    const int sz = rs & 15;
+                    int val = 0;
+                    if (sz) {
+                        br.refill();
+                        val = br.get(1) ? p1 : m1;
+                    } else if (r != 15) {
+                        eobrun = 1 << r;
+                        if (r) {
+                            br.refill();
+                            eobrun += br.get(r);
+                        }
+                        break;
+                    }
+                    while (k <= se) {
+                        const int pos = ZIGZAG[k];
+                        if (blk[pos] != 0) {
+                            refine(pos);
+                        } else if (--r < 0) {
+                            break;
+                        }
+                        ++k;
+                    }
+                    if (val) {
+                        if (k > 63) return -1;
+                        blk[ZIGZAG[k]] = (int16_t)val;
+                    }
+                }
+            }
+            if (eobrun > 0) {
+                for (; k <= se; ++k) refine(ZIGZAG[k]);
+                --eobrun;
+            }
+            return 0;
+        };
+
+        int to_restart = sc.restart_interval;
+        auto restart_if_due = [&]() {
+            if (sc.restart_interval && to_restart == 0) {
+                br.acc = 0;
+                br.nbits = 0;
+                br.hit_marker = false;
+                if (br.p + 1 < br.end && br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7) br.p += 2;
+                pred[0] = pred[1] = pred[2] = 0;
+                eobrun = 0;
+                to_restart = sc.restart_interval;
+            }
+        };
+        if (sc.ns > 1) {                                     // interleaved scan: MCU order
+            for (int my = 0; my < P.mcus_y; ++my)
+                for (int mx = 0; mx < P.mcus_x; ++mx) {
+                    restart_if_due();
+                    for (int i = 0; i < sc.ns; ++i) {
+                        const int c = sc.comp[i];
+                        for (int by = 0; by < P.comp[c].v; ++by)
+                            for (int bx = 0; bx < P.comp[c].h; ++bx) {
+                                const long brow = (long)my * P.comp[c].v + by, bcol = (long)mx * P.comp[c].h + bx;
+                                if (block(i, coef + D.coef_off[c] + (brow * D.blocks_w[c] + bcol) * 64) != 0) {
+                                    vip_set_error("jpeg: corrupt Huffman code in a progressive scan");
+                                    return VIP_ERR_JPEG;
+                                }
+                            }
+                    }
+                    if (sc.restart_interval) --to_restart;
+                }
+        } else {                                             // one component: its own raster of ceil(size / 8) blocks
+            const int c = sc.comp[0];
+            const int cw = (P.width * P.comp[c].h + P.hmax - 1) / P.hmax, chh = (P.height * P.comp[c].v + P.vmax - 1) / P.vmax;
+            const int bw = (cw + 7) / 8, bh = (chh + 7) / 8;
+            for (int y = 0; y < bh; ++y)
+                for (int x = 0; x < bw; ++x) {
+                    restart_if_due();
+                    if (block(0, coef + D.coef_off[c] + ((long)y * D.blocks_w[c] + x) * 64) != 0) {
+                        vip_set_error("jpeg: corrupt Huffman code in a progressive scan");
+                        return VIP_ERR_JPEG;
+                    }
+                    if (sc.restart_interval) --to_restart;
+                }
+        }
+    }
+    return VIP_OK;
+}
+
 int decode_image(const Parsed& P, const vip_jpeg_desc& D, int16_t* coef) {
+    if (!P.scans.empty()) {
+        for (int c = 0; c < P.ncomp; ++c)
+            if (!P.qt_present[P.comp[c].tq]) {
+                vip_set_error("jpeg: missing quantisation table");
+                return VIP_ERR_JPEG;
+            }
+        return decode_scans(P, D, coef);
+    }
     for (int c = 0; c < P.ncomp; ++c) {
         if (!P.qt_present[P.comp[c].tq] || !P.dc[P.comp[c].td].present || !P.ac[P.comp[c].ta].present) {
             vip_set_error("jpeg: missing quantisation / Huffman table");

@@ -30,7 +30,7 @@ def bicubic_table(device) -> torch.Tensor:
 
 def entropy_decode(jpegs: Sequence[bytes], threads: int = 0):
     """Host stage: list of JPEG byte strings -> (desc array (ctypes), coef int16 numpy array).
-    Raises VipError for streams outside the supported baseline subset (the reference raises too: TF)."""
+    Raises VipError for streams outside the supported Huffman subset (SOF0/1/2, 8-bit, 1 or 3 components) (the reference raises too: TF)."""
     lib = _abi.lib()
     n = len(jpegs)
     if threads <= 0:
