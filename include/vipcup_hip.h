@@ -133,9 +133,10 @@ int vip_se_gate_f16(const void* x, const void* w1, const float* b1, const void* 
  * Depthwise Conv2D k x k (+bias)(+act).  Replaces tf.keras.layers.DepthwiseConv2D:
  *   gcvit/layers/feature.py:93,133 ; tfimm/architectures/convnext.py:192-198 ;
  *   kecam efficientnet_v2.py:85 (common_layers.py:251-265).
- *   w [kh][kw][C] f16 ; bias [C] f32 or NULL ; C % 8 == 0.
+ *   w [kh][kw][C] f32 (k*k taps per channel: there is no K-long sum for rounding errors to average out in, and the
+ *   filter is a few KB, so it stays in full precision) ; bias [C] f32 or NULL ; C % 8 == 0.
  * ------------------------------------------------------------------------------------------ */
-int vip_dwconv2d_nhwc_f16(const void* x, const void* w, const float* bias, void* y,
+int vip_dwconv2d_nhwc_f16(const void* x, const float* w, const float* bias, void* y,
                           int B, int H, int W, int C, int k, int stride, int pt, int pl,
                           int Ho, int Wo, int act, void* stream);
 

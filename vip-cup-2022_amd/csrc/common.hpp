@@ -35,7 +35,7 @@ static inline int vip_launch_status(const char* what) {
 }
 
 // stride-1 depthwise fast path (dwconv.hip); returns 1 when the shape is not handled there
-int vip_dwconv_tiled(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int k,
+int vip_dwconv_tiled(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                      int pt, int pl, int Ho, int Wo, int act, hipStream_t s);
 
 // ---- device helpers -------------------------------------------------------------------------

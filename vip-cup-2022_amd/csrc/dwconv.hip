@@ -39,7 +39,7 @@ __device__ __forceinline__ void dw_store(f32x2 (&acc)[T][TW][4], const float (&b
 }
 
 template <int K, int T, int TW, bool WHOLE>
-__global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+__global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, f16* __restrict__ y,
                                                              int B, int H, int W, int C, int pt, int pl, int Ho,
                                                              int Wo, int act, int cb_chunks, int tiles_x, int tiles_y,
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
     // stage the filter slice as fp32
     for (int i = threadIdx.x; i < K * K * nch * 8; i += 256) {
         const int tap = i / (nch * 8), c = i - tap * (nch * 8);
-        wlds[tap * (cb_chunks * 8) + c] = (float)w[(long)tap * C + c8_0 * 8 + c];
+        wlds[tap * (cb_chunks * 8) + c] = w[(long)tap * C + c8_0 * 8 + c];
     }
     __syncthreads();
 
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
 }
 
 template <int K, int T, int TW, bool WHOLE>
-int launch_tile(const f16* x, const f16* w, const float* bias, f16* y, int B, int H, int W, int C, int pt, int pl,
+int launch_tile(const f16* x, const float* w, const float* bias, f16* y, int B, int H, int W, int C, int pt, int pl,
                 int Ho, int Wo, int act, hipStream_t s) {
     const int C8 = C / 8;
     // channel chunks per block: a divisor-friendly width <= 16 chunks (128 channels) that wastes few lanes
@@ -209,10 +209,10 @@ int launch_tile(const f16* x, const f16* w, const float* bias, f16* y, int B, in
 }  // namespace
 
 // stride-1 fast path; returns 1 if the shape is not handled here
-int vip_dwconv_tiled(const void* x, const void* w, const float* bias, void* y, int B, int H, int W, int C, int k,
+int vip_dwconv_tiled(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                      int pt, int pl, int Ho, int Wo, int act, hipStream_t s) {
     const f16* xi = (const f16*)x;
-    const f16* wi = (const f16*)w;
+    const float* wi = w;
     f16* yo = (f16*)y;
     const long gx = ((long)B * ((Wo + 1) / 2) * ((Ho + 1) / 2) + 15) / 16;
     if (gx >= (1L << 31) || 2L * B * H * W * C >= 0xFFFFFFF0L) return 1;

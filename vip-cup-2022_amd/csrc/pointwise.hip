@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
 // depthwise conv: thread = TW consecutive output columns x 8 channels
 // ---------------------------------------------------------------------------------------------
 template <int K, int S, int TW>
-__global__ __launch_bounds__(256) void dwconv_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+__global__ __launch_bounds__(256) void dwconv_kernel(const f16* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, f16* __restrict__ y, int B,
                                                      int H, int W, int C8, int pt, int pl, int Ho, int Wo, int act) {
     constexpr int NCOL = (TW - 1) * S + K;
@@ -221,12 +221,13 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const f16* __restrict__ x, 
             }
 #pragma unroll
             for (int s = 0; s < K; ++s) {
-                U4H8 wv;
-                wv.u = *reinterpret_cast<const uint4*>(w + (long)(r * K + s) * C + c8 * 8);
+                const float4 w0 = *reinterpret_cast<const float4*>(w + (long)(r * K + s) * C + c8 * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(w + (long)(r * K + s) * C + c8 * 8 + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
                 for (int t = 0; t < TW; ++t)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[t][j] += (float)col[t * S + s].e[j] * (float)wv.e[j];
+                    for (int j = 0; j < 8; ++j) acc[t][j] += (float)col[t * S + s].e[j] * wv[j];
             }
         }
         float bv[8];
@@ -318,7 +319,7 @@ extern "C" int vip_layernorm_f16(const void* x, const float* gamma, const float*
     return vip_launch_status("vip_layernorm_f16");
 }
 
-extern "C" int vip_dwconv2d_nhwc_f16(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
+extern "C" int vip_dwconv2d_nhwc_f16(const void* x, const float* w, const float* bias, void* y, int B, int H, int W,
                                      int C, int k, int stride, int pt, int pl, int Ho, int Wo, int act, void* stream) {
     VIP_REQUIRE(x && w && y, VIP_ERR_BAD_ARG, "vip_dwconv2d_nhwc_f16: null pointer");
     VIP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && pt >= 0 && pl >= 0 && (unsigned)act <= 4u,
@@ -327,7 +328,7 @@ extern "C" int vip_dwconv2d_nhwc_f16(const void* x, const void* w, const float* 
     const int C8 = C / 8;
     hipStream_t s = (hipStream_t)stream;
     const f16* xi = (const f16*)x;
-    const f16* wi = (const f16*)w;
+    const float* wi = w;
     f16* yo = (f16*)y;
     if (stride == 1) {
         const int st = vip_dwconv_tiled(x, w, bias, y, B, H, W, C, k, pt, pl, Ho, Wo, act, s);
