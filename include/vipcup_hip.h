@@ -81,9 +81,10 @@ int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, const v
 /* ------------------------------------------------------------------------------------------
  * vip_conv2d_nhwc_f16 with a squeeze-excite gate folded into the activation load:
  *   y = epilogue( conv1x1( x[b,h,w,c] * gate[b,c] ) )
- * gate [B][Cin] f16 (the output of vip_se_gate_f16).  The product is rounded to fp16 once, exactly as
- * vip_scale_add_act_f16 would have written it, so the result is bit-identical to scale-then-conv without the extra
- * read+write of the expanded tensor.  Replaces `Multiply()([inputs, se])` + the projection Conv2D of kecam se_module
+ * gate [B][2][Cin] f16: the split output of vip_se_gate_f16 / vip_gemm_split_f16 (hi = fp16(g), lo = fp16(g - hi)).
+ * The operand is fma(x, hi, x * lo) in fp16 - one rounding per element, exactly what vip_scale_add_act3_f16 with two
+ * scale planes would have written, so the result is bit-identical to scale-then-conv without the extra read+write of
+ * the expanded tensor.  Replaces `Multiply()([inputs, se])` + the projection Conv2D of kecam se_module
  * (common_layers.py:328-332 with efficientnet_v2.py:97-101) and of gcvit/layers/feature.py:66-70,135-137.
  * Only 1x1 stride-1 ungrouped convolutions whose epilogue is (activation) or (residual [+ReLU]) are accepted
  * (VIP_ERR_UNSUPPORTED otherwise: scale with vip_scale_add_act_f16, then vip_conv2d_nhwc_f16).
@@ -97,6 +98,12 @@ int vip_conv2d_gated_nhwc_f16(const void* x, const void* gate, const void* w, co
 int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const void* residual,
                           void* C, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                           int act_pre, int act_post, void* stream);
+
+/* Few-row Dense with a SPLIT fp16 output:  v = act(A[M,K] @ W[N,K]^T + bias);  C[m][0][n] = fp16(v), C[m][1][n] =
+ * fp16(v - fp16(v)), C is [M][2][N] f16.  For the last layer of a squeeze-excite block whose matrices are too large for
+ * vip_se_gate_f16 (resnet_rs_model.py:167-180 at 1024/2048 channels): the gate keeps ~22 bits.  M <= 256, N % 4 == 0. */
+int vip_gemm_split_f16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda,
+                       int ldw, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused two-layer MLP:  y[M,C] = W2 . act(W1 . LN(x) + b1) + b2 (+ residual), hidden tensor never written to memory.
@@ -122,12 +129,14 @@ int vip_mlp_fused_f16(const void* x, const float* ln_gamma, const float* ln_beta
  *   kecam common_layers.py:311-332 (se_module), resnet_rs_model.py:145-183 (SE),
  *   gcvit/layers/feature.py:46-70 (SE), kecam resnest/resnest.py:44-57 (split-attention gate).
  *   x [B][HW][ldx] f16 ; w1 [Cr][ldw1] f16, b1 [Cr] f32 or NULL ; w2 [Cout][ldw2] f16, b2 [Cout] f32 or NULL ;
- *   gate [B][Cout] f16.  C, Cr multiples of 8 (pad with zero weights).  The pooled and hidden vectors are rounded
- *   to fp16 exactly where vip_global_avgpool_f16 + 2 x vip_gemm_bias_act_f16 round them.
+ *   gate [B][Cout] f16 (split = 0) or [B][2][Cout] f16 (split = 1: hi = fp16(g), lo = fp16(g - hi)).  C, Cr multiples
+ *   of 8 (pad with zero weights).  The pooled and hidden vectors stay fp32.  A gate multiplies a whole channel map, so
+ *   its rounding error does not average out over pixels the way an activation's does: the split form is what
+ *   vip_conv2d_gated_nhwc_f16 and vip_scale_add_act3_f16 consume.
  * ------------------------------------------------------------------------------------------ */
 int vip_se_gate_f16(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* gate,
                     int B, int HW, int C, int ldx, int Cr, int ldw1, int Cout, int ldw2, int act1, int act2,
-                    void* stream);
+                    int split, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Depthwise Conv2D k x k (+bias)(+act).  Replaces tf.keras.layers.DepthwiseConv2D:
@@ -173,11 +182,17 @@ int vip_scale_add_act_f16(const void* x, const void* scale, const void* residual
  * back): NormFreeNet's block needs both x_{l+1} and act(x_{l+1}) (kecam nfnets.py:116-168).  y2 may be NULL. */
 int vip_scale_add_act2_f16(const void* x, const void* scale, const void* residual, void* y, void* y2,
                            int B, int HW, int C, int act, int act2, void* stream);
+/* Same with the scale as scale_planes fp16 planes [B][scale_planes][C] that are summed in fp32 (2 = a split gate). */
+int vip_scale_add_act3_f16(const void* x, const void* scale, int scale_planes, const void* residual, void* y, void* y2,
+                           int B, int HW, int C, int act, int act2, void* stream);
 
 /* ResNeSt split-attention combine (kecam resnest/resnest.py:57-61): out[b,p,c] = sum_r x[b,p,r*C+c] *
  * scale[b,r*C+c].  x f16 [B,HW,radix*C]; scale f16 [B,radix*C] (the r-softmax weights); out [B,HW,C]. */
 int vip_radix_combine_f16(const void* x, const void* scale, void* y, int B, int HW, int C, int radix,
                           void* stream);
+/* Same with the weights as scale_planes fp16 planes [B][scale_planes][radix*C] summed in fp32 (2 = split, see vip_se_gate_f16). */
+int vip_radix_combine2_f16(const void* x, const void* scale, int scale_planes, void* y, int B, int HW, int C, int radix,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GCViT window attention core (gcvit/layers/attention.py:52-83, window.py:3-15):

@@ -14,11 +14,11 @@ BIAS_CORRECT = False     # add (W32 - W16) . E[x] to every conv/dense output (wh
 ACTN = {0: None, 1: "relu", 2: "silu", 3: "gelu", 4: "sigmoid", None: None}
 
 
-SKIP_ROUND = set()       # diagnostic: operator tags whose outputs are NOT rounded (conv, conv_res, dense, dw, saa, gap, gate_mul, ln, pool, attn)
+SKIP_ROUND = set()       # diagnostic: operator tags whose outputs are NOT rounded (conv, conv_res, dense, se_hid, se_gate, dw, saa, gap, gate_mul, ln, pool, attn)
 
 
 def _r(t, tag="other"):
-    return t.to(torch.float16).to(torch.float32) if (ROUND_ACT and tag not in SKIP_ROUND) else t
+    return t.to(torch.float16).to(torch.float32) if (ROUND_ACT and tag is not None and tag not in SKIP_ROUND) else t
 
 
 def _an(a):
@@ -34,7 +34,7 @@ def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=
            gate=None):
     xx = x[..., cin_off:cin_off + cw.cin]
     if gate is not None:
-        xx = _r(xx * gate[:, None, None, :], "gate_mul")
+        xx = _r(xx * _gate(gate)[:, None, None, :], "gate_mul")
     y = R.conv2d(xx, _w(cw), cw.bias, stride, pad, cw.groups)
     if BIAS_CORRECT and cw.err is not None:
         mu = xx.reshape(-1, xx.shape[-1]).mean(0)                                  # [Cin]
@@ -53,14 +53,14 @@ def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=
     return y
 
 
-def dense(x, cw, act=None, act_post=None, residual=None):
+def dense(x, cw, act=None, act_post=None, residual=None, tag="dense"):
     y = x @ _w(cw)[0, 0] + (cw.bias if cw.bias is not None else 0)
     if BIAS_CORRECT and cw.err is not None:
         y = y + cw.err[:, :x.shape[-1]] @ x.reshape(-1, x.shape[-1]).mean(0)
     y = R.act(y, _an(act))
     if residual is not None:
         y = y + residual
-    return _r(R.act(y, _an(act_post)), "dense")
+    return _r(R.act(y, _an(act_post)), tag)
 
 
 def mlp(x, fc1, fc2, act="gelu", residual=None, ln=None):
@@ -69,8 +69,26 @@ def mlp(x, fc1, fc2, act="gelu", residual=None, ln=None):
     return dense(dense(x, fc1, act=act), fc2, residual=residual)
 
 
-def se_gate(x, fc1, fc2, act1, act2="sigmoid"):
-    return dense(dense(global_avgpool(x), fc1, act=act1), fc2, act=act2)
+def _gate(g):
+    """[B, 2, C] split gate (or plain [B, C]) -> fp32 [B, C]"""
+    return g[:, 0] + g[:, 1] if g.dim() == 3 else g
+
+
+def _split(v):
+    if not ROUND_ACT or "se_gate" in SKIP_ROUND:
+        return torch.stack([v, torch.zeros_like(v)], 1)
+    hi = v.to(torch.float16).to(torch.float32)
+    return torch.stack([hi, (v - hi).to(torch.float16).to(torch.float32)], 1)
+
+
+def se_gate(x, fc1, fc2, act1, act2="sigmoid", split=True):
+    # the fused kernel keeps the pooled and hidden vectors in fp32; the wide-gate path rounds them (tags gap / se_hid)
+    fused = x.shape[-1] * fc1.cout + fc1.cout * fc2.cout <= 256 * 1024
+    pooled = x.reshape(x.shape[0], -1, x.shape[-1]).mean(1) if fused else global_avgpool(x)
+    hid = dense(pooled, fc1, act=act1, tag=None if fused else "se_hid")
+    if not split:
+        return dense(hid, fc2, act=act2, tag="se_gate")
+    return _split(dense(hid, fc2, act=act2, tag=None))
 
 
 def dwconv2d(x, w_khwc, bias, k, stride=1, pad=(0, 0, 0, 0), act=None):
@@ -115,6 +133,7 @@ def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
         return y, _r(R.act(y, _an(act2)), "saa")
     y = x
     if scale is not None:
+        scale = _gate(scale)
         y = y * scale.reshape(scale.shape[0], *([1] * (x.dim() - 2)), scale.shape[-1])
     if residual is not None:
         y = y + residual
@@ -123,7 +142,7 @@ def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
 
 def radix_combine(x, scale, radix=2):
     B, H, W, RC = x.shape
-    return _r((x * scale[:, None, None, :]).reshape(B, H, W, radix, RC // radix).sum(3))
+    return _r((x * _gate(scale)[:, None, None, :]).reshape(B, H, W, radix, RC // radix).sum(3))
 
 
 def window_attention(qkv, q_global, table, heads, ws, scale):

@@ -51,10 +51,15 @@ def test_argument_checks_do_not_need_a_gpu():
     st = lib.vip_mlp_fused_f16(p, p, None, 1e-6, p, None, p, None, None, p, 100000, 96, 384, 96, 96, 384, 96, 0, 3, None)
     assert st == -1 and b"ln_gamma" in lib.vip_last_error()
     # SE gate: alignment and width limits
-    st = lib.vip_se_gate_f16(p, p, None, p, None, p, 4, 49, 100, 100, 8, 104, 100, 8, 2, 4, None)
+    st = lib.vip_se_gate_f16(p, p, None, p, None, p, 4, 49, 100, 100, 8, 104, 100, 8, 2, 4, 1, None)
     assert st == -2
-    st = lib.vip_se_gate_f16(p, p, None, p, None, p, 4, 49, 32768, 32768, 8, 32768, 32768, 8, 2, 4, None)
+    st = lib.vip_se_gate_f16(p, p, None, p, None, p, 4, 49, 32768, 32768, 8, 32768, 32768, 8, 2, 4, 1, None)
     assert st == -3 and b"too wide" in lib.vip_last_error()
+    # split-output Dense: a batch of pooled vectors, at most 256 rows
+    st = lib.vip_gemm_split_f16(p, p, None, p, 257, 64, 64, 64, 64, 4, None)
+    assert st == -3 and b"256" in lib.vip_last_error()
+    st = lib.vip_scale_add_act3_f16(p, p, 3, None, p, None, 1, 4, 8, 0, 0, None)
+    assert st == -1 and b"scale_planes" in lib.vip_last_error()
     # gated conv: only pointwise convolutions take a gate
     d = _abi.ConvDesc(B=1, H=8, W=8, Cin=16, Cout=16, kh=3, kw=3, sh=1, sw=1, pt=1, pl=1, Ho=8, Wo=8, groups=1, ldx=16,
                       cin_off=0, ldy=16, cout_off=0, ldr=0, res_off=0, ldw=144, act_pre=0, act_post=0)

@@ -22,8 +22,8 @@ N_IMG = 16
 # calibrated heads turn a 1e-3 relative feature error into up to 3e-2 on a logit whose spread over images is 1.5
 # (the synthetic backbones map all images to nearly the same feature vector; DESIGN.md "Numerics").
 # The tolerances below are what the fp16 path must hold; the measured values are logged to parity.log.
-TOL_MEMBER_LOGIT = 5e-2   # per member, calibrated logit (std 1.5 over the image set): <= 3.3 % of the spread
-TOL_ENSEMBLE_PROB = 2e-3  # ensemble-mean probability (what the 0.487 threshold is applied to)
+TOL_MEMBER_LOGIT = 2e-2   # per member, calibrated logit (std 1.5 over the image set); measured: 0.8e-3 .. 8.4e-3
+TOL_ENSEMBLE_PROB = 1e-3  # ensemble-mean probability = the score main.py thresholds at 0.487 (north_star: 1e-3); measured 2.7e-4
 
 
 def _logit(p):

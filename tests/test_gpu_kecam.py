@@ -17,6 +17,12 @@ def test_radix_combine(report):
     s = h(torch.rand(2, 128, generator=g))
     refv = (x * s[:, None, None, :]).reshape(2, 5, 6, 2, 64).sum(3)
     check(report, "radix_combine", ops.radix_combine(dev(x), dev(s), 2), refv)
+    from tests.test_gpu_ops import split_gate
+    s32 = torch.rand(2, 128, generator=g)                      # weights that are not fp16 numbers, as two planes
+    ref2 = (x * s32[:, None, None, :]).reshape(2, 5, 6, 2, 64).sum(3)
+    got2 = ops.radix_combine(dev(x), split_gate(s32), 2)
+    check(report, "radix_combine split", got2, ref2)
+    assert torch.equal(got2.cpu().float(), h(ref2)) or (got2.cpu().float() - h(ref2)).abs().max() <= 2e-3   # correctly rounded up to fp32 sum order
 
 
 @pytest.mark.parametrize("key", ["resnest50", "efficientnet_v2t", "efficientnet_v1b4", "eca_nfnet_l0"])

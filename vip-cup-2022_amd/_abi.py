@@ -44,7 +44,8 @@ SIGNATURES = {
     "vip_gemm_bias_act_f16": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "vip_mlp_fused_supported": (_i, [_i, _i, _i, _i]),
     "vip_mlp_fused_f16": (_i, [_vp, _vp, _vp, _f] + [_vp] * 6 + [_i] * 9 + [_vp]),
-    "vip_se_gate_f16": (_i, [_vp] * 6 + [_i] * 10 + [_vp]),
+    "vip_se_gate_f16": (_i, [_vp] * 6 + [_i] * 11 + [_vp]),
+    "vip_gemm_split_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 6 + [_vp]),
     "vip_dwconv2d_nhwc_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
     "vip_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "vip_pool2d_nhwc_f16": (_i, [_vp, _vp] + [_i] * 13 + [_vp]),
@@ -52,7 +53,9 @@ SIGNATURES = {
     "vip_gap_dense_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vip_scale_add_act_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_scale_add_act2_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vip_scale_add_act3_f16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vip_radix_combine_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vip_radix_combine2_f16": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "vip_window_attn_fwd_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _vp]),
     "vip_mhsa_fwd_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "vip_jpeg_probe_h": (_i, [_vp, _sz, _vp, _vp]),

@@ -42,7 +42,8 @@ struct ConvArgs {
     int bias_elems;
     int act_pre, act_post;
     int m_blocks, n_blocks;
-    const f16* gate;   // optional per-image input-channel gate [B][K] (squeeze-excite scale folded into the load); pwk only
+    const f16* gate;   // optional per-image input-channel gate [B][2][K] (hi, lo planes of a squeeze-excite scale, folded into the load); pwk only
+    int y_lo_off;      // rows kernel: != 0 -> also write fp16(v - fp16(v)) this many halfs after each output (split gate)
     int gate_hw;       // pixels per image (image index of pixel m = m / gate_hw)
 };
 
@@ -537,15 +538,15 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
         const int m = m0 + p * 16 + l15;
         x_off[p] = m < a.M ? (unsigned)((m * a.ldx + lq * 8) * 2) : 0xFFFF0000u;   // + k bytes stays out of range
     }
-    // squeeze-excite gate folded into the activation operand: x[m, k] * gate[image(m), k], the fp16 product rounded
-    // once - bit-identical to scale_add_act writing x * gate as fp16 and this kernel reading it back
+    // squeeze-excite gate folded into the activation operand: x[m, k] * (hi + lo)[image(m), k] as fma(x, hi, x * lo) in
+    // packed fp16 - the product is rounded once, per element; the gate itself carries ~22 bits (see se_gate.hip)
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.gate, 0, GATED ? (unsigned)min((long)0xFFFFFFF0L, 2L * ((a.M + a.gate_hw - 1) / a.gate_hw) * a.K) : 0u, 0x00020000);
+        (void*)a.gate, 0, GATED ? (unsigned)min((long)0xFFFFFFF0L, 4L * ((a.M + a.gate_hw - 1) / a.gate_hw) * a.K) : 0u, 0x00020000);
     unsigned g_off[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int m = m0 + p * 16 + l15;
-        g_off[p] = (GATED && m < a.M) ? (unsigned)(((m / a.gate_hw) * a.K + lq * 8) * 2) : 0xFFFF0000u;
+        g_off[p] = (GATED && m < a.M) ? (unsigned)(((m / a.gate_hw) * 2 * a.K + lq * 8) * 2) : 0xFFFF0000u;
     }
     const int nk = (a.K + 63) >> 6;
 
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + w_lds[i]) = wst[i];
     };
-    U4H8 xf[2][PT], gf[GATED ? 2 : 1][GATED ? PT : 1];
+    U4H8 xf[2][PT], gq[GATED ? 2 : 1][GATED ? PT : 1];      // gq: the gate planes (hi, lo) of ONE k-step
     auto load_x = [&](int kc, int ks) {
         // weights of the K tail are zero in LDS, but 0 * (Inf/NaN garbage of the next row) is NaN: mask the lanes
         const bool ok = kc * 64 + ks * 32 + lq * 8 < a.K;
@@ -568,11 +569,28 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
         for (int p = 0; p < PT; ++p)
             xf[ks][p].u = __builtin_bit_cast(
                 uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + kc * 128 + ks * 64 : OOB, 0, 0));
+    };
+    // Gate fragments run one k-step ahead of their use in ONE register set (a second prefetched set does not fit next to
+    // the accumulators): gate_x(ks) folds them into xf[ks] - fma(x, hi, x * lo) in packed fp16 - and the set is
+    // re-requested at once for the following k-step, landing under the MFMAs in between.  The buffer is [B][2][K]
+    // halfs, L1/L2-resident.
+    auto load_g = [&](int kc, int ks) {
+        if constexpr (GATED) {
+            const bool ok = kc * 64 + ks * 32 + lq * 8 < a.K;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                gq[0][p].u = __builtin_bit_cast(
+                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? g_off[p] + kc * 128 + ks * 64 : OOB, 0, 0));
+                gq[1][p].u = __builtin_bit_cast(
+                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? g_off[p] + kc * 128 + ks * 64 + 2 * a.K : OOB, 0, 0));
+            }
+        }
+    };
+    auto gate_x = [&](int ks) {
         if constexpr (GATED) {
 #pragma unroll
-            for (int p = 0; p < PT; ++p)
-                gf[ks][p].u = __builtin_bit_cast(
-                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? g_off[p] + kc * 128 + ks * 64 : OOB, 0, 0));
+            for (int p = 0; p < PT; ++p)                                              // 4 x (v_pk_mul_f16 + v_pk_fma_f16)
+                xf[ks][p].h = __builtin_elementwise_fma(xf[ks][p].h, gq[0][p].h, xf[ks][p].h * gq[1][p].h);
         }
     };
 
@@ -593,15 +611,12 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
     load_w(0);
     load_x(0, 0);
     load_x(0, 1);
+    load_g(0, 0);
     store_w(0);
     __syncthreads();
 
     auto compute = [&](int buf, int ks) {
         const char* ws = smem + buf * STAGE + l15 * ROWB + lq * 16 + ks * 64;
-        if constexpr (GATED) {
-#pragma unroll
-            for (int p = 0; p < PT; ++p) xf[ks][p].h = xf[ks][p].h * gf[ks][p].h;     // 4 x v_pk_mul_f16
-        }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             U4H8 wf[4];
@@ -624,10 +639,22 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
         const int buf = kc & 1;
         load_w(kc + 1);
         __builtin_amdgcn_sched_barrier(0);   // pin the issue points: the scheduler otherwise sinks every load below
-        compute(buf, 0);                     // the MFMAs, right in front of its wait
+        if constexpr (GATED) {               // the MFMAs, right in front of its wait
+            gate_x(0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_g(kc, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        compute(buf, 0);
         __builtin_amdgcn_sched_barrier(0);
         load_x(kc + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (GATED) {
+            gate_x(1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_g(kc + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         compute(buf, 1);
         __builtin_amdgcn_sched_barrier(0);
         load_x(kc + 1, 1);
@@ -655,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
 }
 
 
-template <int NG, bool GATED, int WN, bool IM2COL>
+template <int NG, int WN, bool IM2COL>
 __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(ConvArgs a, int mode) {
     // IM2COL: the same kernel for k x k / strided / grouped convolutions - only the activation staging changes (each
     // 16-byte chunk of a k-chunk belongs to one filter tap: the lane's tap and channel come from one division per
@@ -751,18 +778,6 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
             hw0[i] = hi0 * 65536 + (wi0 & 0xFFFF);
         }
     }
-    // squeeze-excite gate folded into the activation operand: x[m, k] * gate[image(m), k], the fp16 product rounded
-    // once - bit-identical to scale_add_act writing x * gate as fp16 and this kernel reading it back
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.gate, 0, GATED ? (unsigned)min((long)0xFFFFFFF0L, 2L * ((a.M + a.gate_hw - 1) / a.gate_hw) * a.K) : 0u, 0x00020000);
-    unsigned g_off[GATED ? X_IT : 1];
-    if constexpr (GATED) {
-#pragma unroll
-        for (int i = 0; i < X_IT; ++i) {
-            const int m = mblk + xr + XROWS * i;
-            g_off[i] = m < a.M ? (unsigned)(((m / a.gate_hw) * a.K + xc * 8) * 2) : 0xFFFF0000u;
-        }
-    }
     const int nk = (a.K + 63) >> 6;
 
     uint4 wst[W_IT];
@@ -776,7 +791,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
 #pragma unroll
         for (int i = 0; i < W_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + w_lds[i]) = wst[i];
     };
-    U4H8 xst[X_IT], gst[GATED ? X_IT : 1];
+    U4H8 xst[X_IT];
     auto load_x = [&](int kc) {
         // weights of the K tail are zero in LDS, but 0 * (Inf/NaN garbage of the next row) is NaN: mask the lanes
         const bool kok = kc * 64 + xc * 8 < a.K;
@@ -799,17 +814,10 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
                     uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_base + i * x_rstep + kc * 128 : OOB, 0, 0));
             }
         }
-        if constexpr (GATED) {
-#pragma unroll
-            for (int i = 0; i < X_IT; ++i)
-                gst[i].u = __builtin_bit_cast(
-                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, kok ? g_off[i] + kc * 128 : OOB, 0, 0));
-        }
     };
     auto store_x = [&]() {
 #pragma unroll
         for (int i = 0; i < X_IT; ++i) {
-            if constexpr (GATED) xst[i].h = xst[i].h * gst[i].h;                     // 4 x v_pk_mul_f16
             *reinterpret_cast<uint4*>(ximg + (xr + XROWS * i) * ROWB + xc * 16) = xst[i].u;   // image r/64, row r%64
         }
     };
@@ -912,15 +920,12 @@ int launch_pwk(const ConvArgs& a0, int mode, hipStream_t s) {
     constexpr size_t smem = (2 * 64 * NG * WN + 4 * 64) * 160;     // 2 weight stages + 4 activation images
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, true, WN, false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, false, WN, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, WN, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     const dim3 grid((unsigned)(a.m_blocks * a.n_blocks));
-    if (a.gate) hipLaunchKernelGGL((pwk_gemm_kernel<NG, true, WN, false>), grid, dim3(256 * WN), smem, s, a, mode);
-    else hipLaunchKernelGGL((pwk_gemm_kernel<NG, false, WN, false>), grid, dim3(256 * WN), smem, s, a, mode);
+    hipLaunchKernelGGL((pwk_gemm_kernel<NG, WN, false>), grid, dim3(256 * WN), smem, s, a, mode);
     return vip_launch_status("vip_conv2d_nhwc_f16(pwk)");
 }
 
@@ -932,12 +937,12 @@ int launch_pwk_conv(const ConvArgs& a0, int mode, int groups, hipStream_t s) {
     constexpr size_t smem = (2 * 64 * NG + 4 * 64) * 160;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, false, 1, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwk_gemm_kernel<NG, 1, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
     const dim3 grid((unsigned)(a.m_blocks * a.n_blocks), (unsigned)groups);
-    hipLaunchKernelGGL((pwk_gemm_kernel<NG, false, 1, true>), grid, dim3(256), smem, s, a, mode);
+    hipLaunchKernelGGL((pwk_gemm_kernel<NG, 1, true>), grid, dim3(256), smem, s, a, mode);
     return vip_launch_status("vip_conv2d_nhwc_f16(pwk-im2col)");
 }
 
@@ -1011,15 +1016,25 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(ConvArgs a) {
                    ((a.bias && n < a.Cout_g) ? a.bias[n] : 0.f);
         }
         f16* dst = a.y + (long)m * a.ldy + a.cout_off + n0 + lq * 4;
-        if (n0 + lq * 4 + 3 < a.Cout_g) {
-            f16x4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (f16)vip_act(v[r], a.act_pre);
+        for (int r = 0; r < 4; ++r) v[r] = vip_act(v[r], a.act_pre);
+        if (n0 + lq * 4 + 3 < a.Cout_g) {
+            f16x4 o, ol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = (f16)v[r];
+                ol[r] = (f16)(v[r] - (float)o[r]);
+            }
             *reinterpret_cast<f16x4*>(dst) = o;
+            if (a.y_lo_off) *reinterpret_cast<f16x4*>(dst + a.y_lo_off) = ol;
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (n0 + lq * 4 + r < a.Cout_g) dst[r] = (f16)vip_act(v[r], a.act_pre);
+                if (n0 + lq * 4 + r < a.Cout_g) {
+                    const f16 o = (f16)v[r];
+                    dst[r] = o;
+                    if (a.y_lo_off) dst[a.y_lo_off + r] = (f16)(v[r] - (float)o);
+                }
         }
     }
 }
@@ -1044,7 +1059,7 @@ int launch(const ConvArgs& a0, int groups, hipStream_t s) {
 
 }  // namespace
 
-static int conv2d_impl(const void* x, const void* gate, const void* w, const float* bias, const void* residual, void* y,
+static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void* w, const float* bias, const void* residual, void* y,
                        const vip_conv_desc* d, void* stream) {
     VIP_REQUIRE(x && w && y && d, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_f16: null pointer");
     VIP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 &&
@@ -1087,6 +1102,7 @@ static int conv2d_impl(const void* x, const void* gate, const void* w, const flo
     a.m_blocks = a.n_blocks = 0;
     a.gate = (const f16*)gate;
     a.gate_hw = d->Ho * d->Wo;
+    a.y_lo_off = y_lo_off;
     hipStream_t s = (hipStream_t)stream;
     // HBM-bound shapes (short K): a smaller M tile -> 24-48 KB LDS and half the accumulators -> 3-5 workgroups per
     // CU in flight instead of 2, which is what hides the load -> MFMA -> store latency chain of a 1-4 k-tile block.
@@ -1107,12 +1123,15 @@ static int conv2d_impl(const void* x, const void* gate, const void* w, const flo
             hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)((cout_g + 15) / 16), (unsigned)((M + 63) / 64)), dim3(256), 0, s, a);
             return vip_launch_status("vip_conv2d_nhwc_f16(rows)");
         }
+        VIP_REQUIRE(!y_lo_off, VIP_ERR_UNSUPPORTED, "vip_gemm_split_f16: at most 256 rows, N %% 4 == 0");
         if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) return launch_pw_k<4>(a, mode, s);
         if (mode >= 0 && (pw_mode & 2) && a.x_span_bytes < 0xFFFFFFF0L) {
             // (a 64 x 256 wave tile at one wave per SIMD - NG = 4 - measured 15-40 % slower than NG = 2 at two)
             static const int xl_min_k = getenv("VIP_PWK_XLK") ? atoi(getenv("VIP_PWK_XLK")) : 768;
-            if (a.K < xl_min_k && a.x_span_bytes < 0xFFFF0000L - 2L * a.K)
+            // (gated convolutions: only the direct kernel carries the gate pipeline - their deep-K cases are small launches)
+            if ((a.K < xl_min_k || gate) && a.x_span_bytes < 0xFFFF0000L - 2L * a.K)
                 return cout_g <= 64 ? launch_pwk_direct<1>(a, mode, s) : launch_pwk_direct<2>(a, mode, s);
+            VIP_REQUIRE(!gate, VIP_ERR_UNSUPPORTED, "vip_conv2d_gated_nhwc_f16: input tensor too large (4 GB - 2K)");
             if (cout_g <= 64) return launch_pwk<1, 1>(a, mode, s);
             // 256 x 256 block tiles (8 waves): 5 % on deep-K layers whose N is a multiple of 256; slower whenever the last
             // 256-channel tile is half empty (N = 384: 258 -> 346 us) or K is short
@@ -1141,7 +1160,7 @@ static int conv2d_impl(const void* x, const void* gate, const void* w, const flo
 
 extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                    const vip_conv_desc* d, void* stream) {
-    return conv2d_impl(x, nullptr, w, bias, residual, y, d, stream);
+    return conv2d_impl(x, nullptr, 0, w, bias, residual, y, d, stream);
 }
 
 extern "C" int vip_conv2d_gated_nhwc_f16(const void* x, const void* gate, const void* w, const float* bias,
@@ -1149,7 +1168,7 @@ extern "C" int vip_conv2d_gated_nhwc_f16(const void* x, const void* gate, const 
     VIP_REQUIRE(gate, VIP_ERR_BAD_ARG, "vip_conv2d_gated_nhwc_f16: null gate");
     VIP_REQUIRE(d && d->cin_off == 0 && d->ldx == d->Cin, VIP_ERR_UNSUPPORTED,
                 "vip_conv2d_gated_nhwc_f16: the gate indexes the whole input channel axis (cin_off = 0, ldx = Cin)");
-    return conv2d_impl(x, gate, w, bias, residual, y, d, stream);
+    return conv2d_impl(x, gate, 0, w, bias, residual, y, d, stream);
 }
 
 extern "C" int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const void* residual,
@@ -1160,4 +1179,14 @@ extern "C" int vip_gemm_bias_act_f16(const void* A, const void* W, const float* 
     d.Ho = d.Wo = 1; d.groups = 1; d.ldx = lda; d.cin_off = 0; d.ldy = ldc; d.cout_off = 0; d.ldr = ldr;
     d.res_off = 0; d.ldw = ldw; d.act_pre = act_pre; d.act_post = act_post;
     return vip_conv2d_nhwc_f16(A, W, bias, residual, C, &d, stream);
+}
+
+extern "C" int vip_gemm_split_f16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda,
+                                  int ldw, int act, void* stream) {
+    VIP_REQUIRE(M > 0 && M <= 256, VIP_ERR_UNSUPPORTED, "vip_gemm_split_f16: M=%d (1..256 rows)", M);
+    vip_conv_desc d;
+    d.B = M; d.H = 1; d.W = 1; d.Cin = K; d.Cout = N; d.kh = d.kw = 1; d.sh = d.sw = 1; d.pt = d.pl = 0;
+    d.Ho = d.Wo = 1; d.groups = 1; d.ldx = lda; d.cin_off = 0; d.ldy = 2 * N; d.cout_off = 0; d.ldr = 0;
+    d.res_off = 0; d.ldw = ldw; d.act_pre = act; d.act_post = VIP_ACT_NONE;
+    return conv2d_impl(A, nullptr, N, W, bias, nullptr, C, &d, stream);
 }

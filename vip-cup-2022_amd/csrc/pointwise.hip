@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void gap_kernel(const f16* __restrict__ x, f16
 __global__ __launch_bounds__(256) void scale_add_act_kernel(const f16* __restrict__ x, const f16* __restrict__ sc,
                                                             const f16* __restrict__ res, f16* __restrict__ y,
                                                             f16* __restrict__ y2, long total8, int HW, int C8, int act,
-                                                            int act2) {
+                                                            int act2, int planes) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (long)gridDim.x * 256) {
         const int c8 = (int)(idx % C8);
         const long pix = idx / C8;
@@ -105,9 +105,17 @@ __global__ __launch_bounds__(256) void scale_add_act_kernel(const f16* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = (float)v.e[j];
         if (sc) {
-            s.u = *reinterpret_cast<const uint4*>(sc + ((long)b * C8 + c8) * 8);
+            s.u = *reinterpret_cast<const uint4*>(sc + ((long)b * planes * C8 + c8) * 8);
+            float g[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] *= (float)s.e[j];
+            for (int j = 0; j < 8; ++j) g[j] = (float)s.e[j];
+            if (planes == 2) {   // split gate: hi + lo
+                s.u = *reinterpret_cast<const uint4*>(sc + (((long)b * 2 + 1) * C8 + c8) * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] += (float)s.e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= g[j];
         }
         if (res) {
             r.u = *reinterpret_cast<const uint4*>(res + idx * 8);
@@ -278,16 +286,22 @@ extern "C" int vip_global_avgpool_f16(const void* x, void* y, int B, int HW, int
     return vip_launch_status("vip_global_avgpool_f16");
 }
 
-extern "C" int vip_scale_add_act2_f16(const void* x, const void* scale, const void* residual, void* y, void* y2, int B,
-                                      int HW, int C, int act, int act2, void* stream) {
+extern "C" int vip_scale_add_act3_f16(const void* x, const void* scale, int scale_planes, const void* residual, void* y,
+                                      void* y2, int B, int HW, int C, int act, int act2, void* stream) {
+    VIP_REQUIRE(scale_planes == 1 || scale_planes == 2, VIP_ERR_BAD_ARG, "vip_scale_add_act_f16: scale_planes must be 1 or 2");
     VIP_REQUIRE(x && y, VIP_ERR_BAD_ARG, "vip_scale_add_act_f16: null pointer");
     VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && (unsigned)act <= 4u && (unsigned)act2 <= 4u, VIP_ERR_BAD_ARG,
                 "vip_scale_add_act_f16: bad argument");
     VIP_REQUIRE(C % 8 == 0, VIP_ERR_ALIGNMENT, "vip_scale_add_act_f16: C must be a multiple of 8");
     const long total8 = (long)B * HW * (C / 8);
     hipLaunchKernelGGL(scale_add_act_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
-                       (const f16*)scale, (const f16*)residual, (f16*)y, (f16*)y2, total8, HW, C / 8, act, act2);
+                       (const f16*)scale, (const f16*)residual, (f16*)y, (f16*)y2, total8, HW, C / 8, act, act2, scale_planes);
     return vip_launch_status("vip_scale_add_act_f16");
+}
+
+extern "C" int vip_scale_add_act2_f16(const void* x, const void* scale, const void* residual, void* y, void* y2, int B,
+                                      int HW, int C, int act, int act2, void* stream) {
+    return vip_scale_add_act3_f16(x, scale, 1, residual, y, y2, B, HW, C, act, act2, stream);
 }
 
 extern "C" int vip_scale_add_act_f16(const void* x, const void* scale, const void* residual, void* y, int B, int HW,
@@ -407,7 +421,8 @@ extern "C" int vip_gap_dense_f32(const void* x, const float* W, const float* bia
 // ---------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void radix_combine_kernel(const f16* __restrict__ x, const f16* __restrict__ s,
-                                                            f16* __restrict__ y, long total8, int HW, int C8, int radix) {
+                                                            f16* __restrict__ y, long total8, int HW, int C8, int radix,
+                                                            int planes) {
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (long)gridDim.x * 256) {
         const int c8 = (int)(idx % C8);
         const long pix = idx / C8;
@@ -418,9 +433,17 @@ __global__ __launch_bounds__(256) void radix_combine_kernel(const f16* __restric
         for (int r = 0; r < radix; ++r) {
             U4H8 v, w;
             v.u = *reinterpret_cast<const uint4*>(x + (pix * radix * C8 + (long)r * C8 + c8) * 8);
-            w.u = *reinterpret_cast<const uint4*>(s + (((long)b * radix + r) * C8 + c8) * 8);
+            w.u = *reinterpret_cast<const uint4*>(s + (((long)b * planes * radix + r) * C8 + c8) * 8);
+            float g[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)v.e[j] * (float)w.e[j];
+            for (int j = 0; j < 8; ++j) g[j] = (float)w.e[j];
+            if (planes == 2) {   // split weights: hi + lo
+                w.u = *reinterpret_cast<const uint4*>(s + ((((long)b * 2 + 1) * radix + r) * C8 + c8) * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] += (float)w.e[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v.e[j] * g[j];
         }
         U4H8 o;
 #pragma unroll
@@ -430,13 +453,19 @@ __global__ __launch_bounds__(256) void radix_combine_kernel(const f16* __restric
 }
 }  // namespace
 
-extern "C" int vip_radix_combine_f16(const void* x, const void* scale, void* y, int B, int HW, int C, int radix,
-                                     void* stream) {
+extern "C" int vip_radix_combine2_f16(const void* x, const void* scale, int scale_planes, void* y, int B, int HW, int C,
+                                      int radix, void* stream) {
     VIP_REQUIRE(x && scale && y, VIP_ERR_BAD_ARG, "vip_radix_combine_f16: null pointer");
+    VIP_REQUIRE(scale_planes == 1 || scale_planes == 2, VIP_ERR_BAD_ARG, "vip_radix_combine_f16: scale_planes must be 1 or 2");
     VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && radix > 0, VIP_ERR_BAD_ARG, "vip_radix_combine_f16: non-positive dimension");
     VIP_REQUIRE(C % 8 == 0, VIP_ERR_ALIGNMENT, "vip_radix_combine_f16: C must be a multiple of 8");
     const long total8 = (long)B * HW * (C / 8);
     hipLaunchKernelGGL(radix_combine_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
-                       (const f16*)scale, (f16*)y, total8, HW, C / 8, radix);
+                       (const f16*)scale, (f16*)y, total8, HW, C / 8, radix, scale_planes);
     return vip_launch_status("vip_radix_combine_f16");
+}
+
+extern "C" int vip_radix_combine_f16(const void* x, const void* scale, void* y, int B, int HW, int C, int radix,
+                                     void* stream) {
+    return vip_radix_combine2_f16(x, scale, 1, y, B, HW, C, radix, stream);
 }

@@ -155,7 +155,7 @@ class ResNest(_Base):
                 sc = y
             d = ops.conv2d(y, blk["d1"], act="relu")
             lg = ops.conv2d(d, blk["sa1"], pad=PAD1, act="relu")                # [B,H,W,2*hid]
-            a = ops.se_gate(lg, blk["sa2"], blk["sa3"], "relu", "sigmoid")
+            a = ops.se_gate(lg, blk["sa2"], blk["sa3"], "relu", "sigmoid")      # split: the r-softmax weights keep ~22 bits
             d = ops.radix_combine(lg, a, 2)
             if s > 1:
                 d = ops.pool2d(d, 3, 2, PAD1, ops.POOL_AVG_FULL)

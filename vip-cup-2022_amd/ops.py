@@ -185,8 +185,9 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            cin_off: int = 0, cout_off: int = 0, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = act_post(act(conv(x * gate) + bias) + residual).  ``pad`` = (top, bottom, left, right) zero padding.
-    ``gate`` [B, Cin] fp16 (a squeeze-excite scale) is folded into the activation load of pointwise convolutions;
-    where the C ABI does not take it, x * gate is materialised first - the same fp16 values either way.
+    ``gate`` [B, 2, Cin] fp16 (a split squeeze-excite scale from ``se_gate``) is folded into the activation load of
+    pointwise convolutions; where the C ABI does not take it, x * gate is materialised first - the same fp16 values
+    either way.
     ``x`` may carry more channels than the weight consumes (``cin_off`` selects the slice); ``out`` may
     be a wider tensor written at ``cout_off`` (concat-free channel splits / joins)."""
     _chk16(x, "conv2d.x")
@@ -195,7 +196,7 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
     pt, pb, pl, pr = pad
     if gate is not None:
         _chk16(gate, "conv2d.gate")
-        assert gate.shape == (B, cw.cin) and ldx == cw.cin and cin_off == 0
+        assert gate.shape == (B, 2, cw.cin) and ldx == cw.cin and cin_off == 0
         foldable = gemm_kernel_name(1 << 20, 1 << 20, cw.kh, cw.kw, sh, sw, pad, cw.groups,
                                     True, act, act_post, residual is not None) != "conv_igemm_kernel"
         if _CALIB or not foldable or B * H * W * ldx * 2 >= 0xFFFF0000 - 2 * ldx:
@@ -296,22 +297,40 @@ def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual:
     return dense(dense(x, fc1, act=act), fc2, residual=residual)
 
 
-def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmoid") -> torch.Tensor:
-    """``act2(fc2(act1(fc1(global_avgpool(x)))))`` -> [B, fc2.cout] fp16.
+def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmoid", split: bool = True) -> torch.Tensor:
+    """``g = act2(fc2(act1(fc1(global_avgpool(x)))))`` -> the SPLIT gate [B, 2, fc2.cout] fp16 (``fp16(g)`` and
+    ``fp16(g - fp16(g))``: a gate scales a whole channel map, so its rounding error would not average out over pixels),
+    or with ``split=False`` the plain [B, fc2.cout] fp16 gate.
 
     One launch (vip_se_gate_f16: a workgroup per image, matrix-vector products out of L2) when the two weight matrices
     are small - every image re-reads them, so for wide gates (ResNet-RS / ResNeSt: Cr = C/4) the pool + two batched
-    GEMMs are cheaper and are used instead.  Same rounding points either way."""
+    GEMMs are cheaper and are used instead (the last one with the split epilogue)."""
     _chk16(x, "se_gate.x")
     B, H, W, Cc = x.shape
     assert fc1.groups == 1 and fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1
     assert fc1.cin == Cc and fc2.cin == fc1.cout, (fc1.cin, Cc, fc2.cin, fc1.cout)
     if _CALIB or Cc * fc1.cout + fc1.cout * fc2.cout > 256 * 1024:
-        return dense(dense(global_avgpool(x), fc1, act=act1), fc2, act=act2)
-    out = torch.empty((B, fc2.cout), dtype=torch.float16, device=x.device)
+        hid = dense(global_avgpool(x), fc1, act=act1)
+        return dense_split(hid, fc2, act=act2) if split else dense(hid, fc2, act=act2)
+    out = torch.empty((B, 2, fc2.cout) if split else (B, fc2.cout), dtype=torch.float16, device=x.device)
     st = _abi.lib().vip_se_gate_f16(_p(x), _p(fc1.w), _p(fc1.bias), _p(fc2.w), _p(fc2.bias), _p(out), B, H * W, Cc, Cc,
-                                    fc1.cout, fc1.ldw, fc2.cout, fc2.ldw, _act(act1), _act(act2), _stream())
+                                    fc1.cout, fc1.ldw, fc2.cout, fc2.ldw, _act(act1), _act(act2), int(split), _stream())
     _abi.check(st, "vip_se_gate_f16")
+    return out
+
+
+def dense_split(x: torch.Tensor, cw: ConvWeight, act=None) -> torch.Tensor:
+    """Dense on a few rows ``[M, K]`` with the output as two fp16 planes ``[M, 2, N]`` (``fp16(v)``, ``fp16(v - fp16(v))``)."""
+    _chk16(x, "dense_split.x")
+    M, K = x.shape
+    if _CALIB and cw.err is not None:
+        _bias_correct(cw, x)
+    out = torch.empty((M, 2, cw.cout), dtype=torch.float16, device=x.device)
+    for m0 in range(0, M, 256):       # the C entry point takes at most 256 rows (a batch of pooled vectors)
+        m1 = min(M, m0 + 256)
+        st = _abi.lib().vip_gemm_split_f16(_p(x[m0:m1]), _p(cw.w), _p(cw.bias), _p(out[m0:m1]), m1 - m0, cw.cout, K, K,
+                                           cw.ldw, _act(act), _stream())
+        _abi.check(st, "vip_gemm_split_f16")
     return out
 
 
@@ -383,21 +402,24 @@ def gap_dense_f32(x, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
 
 
 def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
-    """act(x * scale[b,c] + residual); with ``act2`` returns ``(y, act2(y))`` from one launch."""
+    """act(x * scale[b,c] + residual); with ``act2`` returns ``(y, act2(y))`` from one launch.
+    ``scale`` is [B, C] fp16 or a split gate [B, 2, C] (planes summed in fp32)."""
     _chk16(x, "scale_add_act.x")
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
+    planes = 1
     if scale is not None:
         _chk16(scale, "scale_add_act.scale")
-        assert scale.shape == (B, Cc)
+        assert scale.shape in ((B, Cc), (B, 2, Cc)), scale.shape
+        planes = 2 if scale.dim() == 3 else 1
     if residual is not None:
         _chk16(residual, "scale_add_act.residual")
         assert residual.shape == x.shape
     out = torch.empty_like(x)
     out2 = torch.empty_like(x) if act2 is not None else None
-    st = _abi.lib().vip_scale_add_act2_f16(_p(x), _p(scale), _p(residual), _p(out), _p(out2), B, HW, Cc, _act(act),
-                                           _act(act2), _stream())
-    _abi.check(st, "vip_scale_add_act2_f16")
+    st = _abi.lib().vip_scale_add_act3_f16(_p(x), _p(scale), planes, _p(residual), _p(out), _p(out2), B, HW, Cc,
+                                           _act(act), _act(act2), _stream())
+    _abi.check(st, "vip_scale_add_act3_f16")
     return out if act2 is None else (out, out2)
 
 
@@ -471,14 +493,15 @@ def cls_dense_f32(tokens, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
 
 
 def radix_combine(x, scale, radix: int = 2):
-    """ResNeSt split-attention combine: x ``[B,H,W,radix*C]``, scale ``[B,radix*C]`` -> ``[B,H,W,C]``."""
+    """ResNeSt split-attention combine: x ``[B,H,W,radix*C]``, scale ``[B,radix*C]`` or split ``[B,2,radix*C]``
+    -> ``[B,H,W,C]``."""
     _chk16(x, "radix_combine.x")
     _chk16(scale, "radix_combine.scale")
     B, H, W, RC = x.shape
     Cc = RC // radix
-    assert scale.shape == (B, RC)
+    assert scale.shape in ((B, RC), (B, 2, RC)), scale.shape
     out = torch.empty((B, H, W, Cc), dtype=torch.float16, device=x.device)
-    st = _abi.lib().vip_radix_combine_f16(_p(x), _p(scale), _p(out), B, H * W, Cc, radix, _stream())
+    st = _abi.lib().vip_radix_combine2_f16(_p(x), _p(scale), scale.dim() - 1, _p(out), B, H * W, Cc, radix, _stream())
     _abi.check(st, "vip_radix_combine_f16")
     return out
 
