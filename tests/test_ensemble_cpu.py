@@ -33,6 +33,42 @@ def test_shard_bounds_cover_everything():
             assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
 
 
+def test_tta_flags_follow_apply_augment_and_do_not_depend_on_sharding():
+    """dataset/augment.py:153-182: 20 % of the draws leave the image alone; otherwise hflip .5, vflip .5, gray .3"""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ensemble
+    f = ensemble.tta_flags(20000, 3, seed=5)
+    assert f.shape == (3, 20000, 3) and f.dtype == bool
+    assert np.allclose(f.reshape(-1, 3).mean(0), [0.8 * 0.5, 0.8 * 0.5, 0.8 * 0.3], atol=0.01)
+    assert abs((~f.any(-1)).mean() - (0.2 + 0.8 * 0.25 * 0.7)) < 0.01      # untouched: gate off, or all three draws miss
+    assert np.array_equal(f, ensemble.tta_flags(20000, 3, seed=5)) and not np.array_equal(f[0], f[1])
+    assert not np.array_equal(f, ensemble.tta_flags(20000, 3, seed=6))
+
+    # score_files: mean over passes, the same numbers whatever the batch size / shard
+    def jpegs_for(lo, hi):
+        return [bytes([i % 251]) for i in range(lo, hi)]
+
+    def scorer(raws, members, flags=None):
+        ids = torch.tensor([r[0] for r in raws], dtype=torch.float32)
+        base = torch.stack([(ids * (m + 1) % 97) / 97.0 for m in range(len(members))], 0)
+        if flags is None:
+            return base
+        w = torch.tensor(flags.astype(np.float32)) @ torch.tensor([0.1, 0.01, 0.001])      # [tta, n]
+        return base + w.mean(0)[None, :]
+
+    n = 53
+    ref = ensemble.score_files(jpegs_for, n, [(None, None)] * 2, batch_size=64, scorer=scorer, tta=4, tta_seed=9)
+    fl = ensemble.tta_flags(n, 4, 9).astype(np.float32) @ np.array([0.1, 0.01, 0.001], np.float32)
+    plain = ensemble.score_files(jpegs_for, n, [(None, None)] * 2, batch_size=64, scorer=scorer)
+    assert np.allclose(ref, plain + fl.mean(0)[None, :], atol=1e-6)
+    small = ensemble.score_files(jpegs_for, n, [(None, None)] * 2, batch_size=7, scorer=scorer, tta=4, tta_seed=9)
+    assert np.allclose(ref, small, atol=1e-6)
+    lo, hi = ensemble.shard_bounds(n, 1, 2)
+    part = ensemble.score_files(lambda a, b: jpegs_for(a, b), n, [(None, None)] * 2, batch_size=16, rank=1, world=2,
+                                dist=None, scorer=scorer, tta=4, tta_seed=9)
+    assert np.allclose(part, ref[:, lo:hi], atol=1e-6)
+
+
 def _worker(rank, world, port, n, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)

@@ -1135,7 +1135,8 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
             if (cout_g <= 64) return launch_pwk<1, 1>(a, mode, s);
             // 256 x 256 block tiles (8 waves): 5 % on deep-K layers whose N is a multiple of 256; slower whenever the last
             // 256-channel tile is half empty (N = 384: 258 -> 346 us) or K is short
-            if (cout_g % 256 == 0 && a.K >= 1024 && (long)((M + 255) / 256) * (cout_g / 256) >= 256) return launch_pwk<2, 2>(a, mode, s);
+            static const int wn2_min_k = getenv("VIP_PWK_WN2K") ? atoi(getenv("VIP_PWK_WN2K")) : 1024;
+            if (cout_g % 256 == 0 && a.K >= wn2_min_k && (long)((M + 255) / 256) * (cout_g / 256) >= 256) return launch_pwk<2, 2>(a, mode, s);
             return launch_pwk<2, 1>(a, mode, s);
         }
     }

@@ -65,20 +65,44 @@ def all_gather_scores(local: torch.Tensor, counts: List[int], dist=None) -> torc
     return torch.cat([out[r, :, :c] for r, c in enumerate(counts)], dim=1)
 
 
+def tta_flags(n_images: int, tta: int, seed: int = 0) -> np.ndarray:
+    """The random draws of ``apply_augment`` (dataset/augment.py:153-182 with RandomFlip :115-120, RandomGray
+    :142-146) for every (pass, image): bool ``[tta, n_images, 3]`` = (hflip, vflip, gray).  With probability 0.2 an
+    image is left alone (``random_float() > 0.80``), otherwise hflip / vflip with p = 0.5 each and gray with p = 0.3.
+    TensorFlow's RNG stream cannot be reproduced, so the draws come from a seeded numpy generator; they are a function
+    of (seed, pass, image index) only, so the scores do not depend on batch size or on how images are sharded."""
+    out = np.zeros((tta, n_images, 3), dtype=bool)
+    for t in range(tta):
+        u = np.random.default_rng([int(seed), t]).random((n_images, 4))
+        on = ~(u[:, 0] > 0.80)
+        out[t, :, 0] = on & (u[:, 1] < 0.5)
+        out[t, :, 1] = on & (u[:, 2] < 0.5)
+        out[t, :, 2] = on & (u[:, 3] < 0.3)
+    return out
+
+
 def score_files(jpegs_for: Callable[[int, int], List[bytes]], n_images: int, members: List[Tuple[object, object]],
                 batch_size: int = REF_BATCH, rank: int = 0, world: int = 1, dist=None,
-                scorer: Optional[Callable] = None) -> np.ndarray:
+                scorer: Optional[Callable] = None, tta: int = 1, tta_seed: int = 0) -> np.ndarray:
     """Score images [0, n_images) with every member; returns ``[M, n_images]`` fp32 probabilities on every rank.
 
     ``jpegs_for(lo, hi)`` returns the JPEG byte strings of images lo..hi-1 (read lazily, per batch).
     ``members`` = [(spec, model)] with ``spec.input_hw`` and ``model.predict(x) -> [n, C]``.
-    ``scorer(raws, members) -> [M, n]`` replaces the GPU path in the CPU (gloo) tests."""
+    ``tta`` > 1: every image is scored ``tta`` times under ``apply_augment`` draws and the predictions are averaged
+    (main.py:92,109-111, ``CFG.agg = 'mean'``); the JPEGs are still decoded once.
+    ``scorer(raws, members[, flags]) -> [M, n]`` replaces the GPU path in the CPU (gloo) tests."""
     lo, hi = shard_bounds(n_images, rank, world)
     counts = [shard_bounds(n_images, r, world)[1] - shard_bounds(n_images, r, world)[0] for r in range(world)]
+    flags_all = tta_flags(n_images, tta, tta_seed) if tta > 1 else None
     chunks = []
     for b0 in range(lo, hi, batch_size):
-        raws = jpegs_for(b0, min(b0 + batch_size, hi))
-        chunks.append(scorer(raws, members) if scorer is not None else _score_batch(raws, members))
+        b1 = min(b0 + batch_size, hi)
+        raws = jpegs_for(b0, b1)
+        if flags_all is None:
+            chunks.append(scorer(raws, members) if scorer is not None else _score_batch(raws, members))
+        else:
+            fl = flags_all[:, b0:b1]
+            chunks.append(scorer(raws, members, fl) if scorer is not None else _score_batch(raws, members, fl))
     M = len(members)
     if chunks:
         local = torch.cat(chunks, dim=1)
@@ -153,8 +177,10 @@ def default_streams() -> int:
 _MEMBER_STREAMS: Optional[MemberStreams] = None
 
 
-def _score_batch(raws: List[bytes], members) -> torch.Tensor:
-    """decode once -> per member: resize to its resolution, predict, multi->binary.  Returns [M, n] (device)."""
+def _score_batch(raws: List[bytes], members, flags: Optional[np.ndarray] = None) -> torch.Tensor:
+    """decode once -> per member: resize to its resolution, predict, multi->binary.  Returns [M, n] (device).
+    ``flags`` bool [tta, n, 3] (hflip, vflip, gray): one pass per row over augmented copies of the resized batch, mean
+    over passes (the mean commutes with the multi->binary map 1 - p0)."""
     from . import pipeline
     batch = pipeline.decode_jpegs(raws)
     global _MEMBER_STREAMS
@@ -165,8 +191,18 @@ def _score_batch(raws: List[bytes], members) -> torch.Tensor:
         hw = spec.input_hw
         if hw not in cache:
             cache[hw] = batch.resized(hw, hw)
-    rows = []
-    for p in _MEMBER_STREAMS.predict_all(members, cache):   # [n, C] fp32 each
-        p = (1.0 - p[:, 0]) if p.shape[1] > 1 else p[:, 0]  # main.py:113-114
-        rows.append(p.float())
-    return torch.stack(rows, 0)
+    def one_pass(inputs):
+        rows = []
+        for p in _MEMBER_STREAMS.predict_all(members, inputs):   # [n, C] fp32 each
+            p = (1.0 - p[:, 0]) if p.shape[1] > 1 else p[:, 0]   # main.py:113-114
+            rows.append(p.float())
+        return torch.stack(rows, 0)
+
+    if flags is None:
+        return one_pass(cache)
+    acc = None
+    for fl in flags:                                             # augment AFTER decode+resize, as dataset.py:88-99 maps it
+        aug = {hw: pipeline.apply_augment(x, fl[:, 0], fl[:, 1], fl[:, 2]) for hw, x in cache.items()}
+        s = one_pass(aug)
+        acc = s if acc is None else acc + s
+    return acc / float(len(flags))

@@ -38,6 +38,8 @@ def main(argv=None):
     ap.add_argument("--ckpt-cfg", default=os.path.join(HERE, "ckpts", "ckpts.json"))
     ap.add_argument("--batch-size", type=int, default=128)  # main.py:85
     ap.add_argument("--debug", type=int, default=0)         # main.py:82-83: first 100 images
+    ap.add_argument("--tta", type=int, default=1)           # main.py:167: passes under apply_augment, averaged
+    ap.add_argument("--tta-seed", type=int, default=0)
     a = ap.parse_args(argv)
 
     import pandas as pd
@@ -94,7 +96,8 @@ def main(argv=None):
         return out
 
     t0 = time.time()
-    per_model = ensemble.score_files(jpegs_for, len(paths), members, a.batch_size, rank, world, dist)
+    per_model = ensemble.score_files(jpegs_for, len(paths), members, a.batch_size, rank, world, dist,
+                                     tta=a.tta, tta_seed=a.tta_seed)
     uniq, score, decision = ensemble.aggregate(names, per_model)
     if rank == 0:
         pd.DataFrame({"filename": uniq, "logit": decision}).to_csv(a.output_csv, index=False)  # main.py:143-145
