@@ -23,6 +23,13 @@
 #include "common.hpp"
 #include <stdlib.h>
 
+#ifndef VIP_MFMA_PRIO
+#define VIP_MFMA_PRIO 1
+#endif
+#ifndef VIP_MFMA_PRIO_TILE
+#define VIP_MFMA_PRIO_TILE 1
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -260,11 +267,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(sb + swz_w(wrow_base + (nt >> 1) * 32 + (nt & 1) * 4, ch));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[mt].u = *reinterpret_cast<const uint4*>(sa + swz_x(xrow_base + mt * 16, ch));
+            if (VIP_MFMA_PRIO_TILE) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[mt].h, acc[mt][nt], 0, 0, 0);
+            if (VIP_MFMA_PRIO_TILE) __builtin_amdgcn_s_setprio(0);
         }
         if (kt + 1 < nk) store_tiles(buf ^ 1);
         __syncthreads();
@@ -622,11 +631,13 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
             U4H8 wf[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + (g * 64 + nt * 16) * ROWB);
+            if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
                     acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[ks][p].h, acc[g][p][nt], 0, 0, 0);
+            if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
         }
     };
 
@@ -854,11 +865,13 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
             U4H8 wf[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + (g * 64 + nt * 16) * ROWB);
+            if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
                     acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[p].h, acc[g][p][nt], 0, 0, 0);
+            if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
         }
     };
 
