@@ -17,7 +17,7 @@ OBJ_DIR = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
-            "-Wno-unused-result", "-ffp-contract=fast"]
+            "-Wno-unused-result", "-ffp-contract=fast"] + os.environ.get("VIP_EXTRA_CXXFLAGS", "").split()
 
 
 def _sources():
