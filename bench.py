@@ -77,12 +77,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; VIP_DIST_BACKEND=gloo lets several ranks share a card (a rehearsal of the N > 1 control flow on a
+    # one-GPU box - RCCL itself refuses two ranks on one device)
+    backend = os.environ.get("VIP_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     import vipcup_amd  # noqa: F401

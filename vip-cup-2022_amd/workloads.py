@@ -70,10 +70,10 @@ class Workload:
         probs = (self._serial if serial else self.member_streams).predict_all(self.models, cache)
         s = torch.stack(probs, 0).mean(0).reshape(-1)
         if dist is not None and self.world > 1:
-            if self._gather is None:
-                self._gather = torch.empty((self.world, s.numel()), dtype=s.dtype, device=s.device)
+            if self._gather is None:       # flat: the concatenation form every backend accepts (gloo rejects the stacked one)
+                self._gather = torch.empty((self.world * s.numel(),), dtype=s.dtype, device=s.device)
             dist.all_gather_into_tensor(self._gather, s)
-            s = self._gather
+            s = self._gather.view(self.world, -1)
         self.scores = s
         return s
 
