@@ -96,7 +96,7 @@ def dwconv2d(x, w_khwc, bias, k, stride=1, pad=(0, 0, 0, 0), act=None):
 
 
 def layernorm(x, gamma, beta, eps):
-    return _r(R.layernorm(x, gamma, beta, eps))
+    return _r(R.layernorm(x, gamma, beta, eps), "ln")
 
 
 POOL_MAX_ZEROPAD, POOL_AVG_VALID, POOL_AVG_FULL = 0, 1, 2
@@ -104,13 +104,13 @@ POOL_MAX_ZEROPAD, POOL_AVG_VALID, POOL_AVG_FULL = 0, 1, 2
 
 def pool2d(x, k, stride, pad=(0, 0, 0, 0), mode=0):
     if mode == 0:
-        return _r(R.maxpool_valid(x, k, stride, pad))
+        return _r(R.maxpool_valid(x, k, stride, pad), "pool")
     if mode == 2:
-        return _r(R.avgpool_valid(x, k, stride, pad))
+        return _r(R.avgpool_valid(x, k, stride, pad), "pool")
     xp = R.zero_pad(x, pad).permute(0, 3, 1, 2)
     ones = R.zero_pad(torch.ones_like(x[..., :1]), pad).permute(0, 3, 1, 2)
     F = torch.nn.functional
-    return _r((F.avg_pool2d(xp, k, stride) / F.avg_pool2d(ones, k, stride)).permute(0, 2, 3, 1).contiguous())
+    return _r((F.avg_pool2d(xp, k, stride) / F.avg_pool2d(ones, k, stride)).permute(0, 2, 3, 1).contiguous(), "pool")
 
 
 def global_avgpool(x):
@@ -142,7 +142,7 @@ def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
 
 def radix_combine(x, scale, radix=2):
     B, H, W, RC = x.shape
-    return _r((x * _gate(scale)[:, None, None, :]).reshape(B, H, W, radix, RC // radix).sum(3))
+    return _r((x * _gate(scale)[:, None, None, :]).reshape(B, H, W, radix, RC // radix).sum(3), "saa")
 
 
 def window_attention(qkv, q_global, table, heads, ws, scale):
@@ -159,7 +159,7 @@ def window_attention(qkv, q_global, table, heads, ws, scale):
     else:
         q, k, v = win[0], win[1], win[2]
     o = gcvit_ref.window_attention_core(q, k, v, table, ws, scale)
-    return _r(R.window_reverse(o.permute(0, 2, 1, 3).reshape(B_, ws * ws, C), ws, Hp, Wp, C))
+    return _r(R.window_reverse(o.permute(0, 2, 1, 3).reshape(B_, ws * ws, C), ws, Hp, Wp, C), "attn")
 
 
 def mhsa(qkv, heads, scale):
@@ -167,7 +167,7 @@ def mhsa(qkv, heads, scale):
     D = D3 // 3
     q, k, v = qkv.reshape(B, N, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
     attn = torch.softmax(scale * (q @ k.transpose(-1, -2)), dim=-1)
-    return _r((attn @ v).permute(0, 2, 1, 3).reshape(B, N, D))
+    return _r((attn @ v).permute(0, 2, 1, 3).reshape(B, N, D), "attn")
 
 
 def vit_tokens(patches, cls, pos):
