@@ -119,3 +119,13 @@ def test_unsupported_streams_are_rejected():
         pipeline.entropy_decode([bytes(raw)])
     with pytest.raises(_abi.VipError):
         pipeline.entropy_decode([b"not a jpeg at all"])
+    raw = bytearray(synth_jpeg(3))
+    i = raw.find(b"\xff\xc0")
+    raw[i + 5:i + 9] = b"\xff\xff\xff\xff"             # the frame header claims 65535 x 65535
+    with pytest.raises(_abi.VipError, match="VIP_MAX_JPEG_PIXELS"):
+        pipeline.entropy_decode([bytes(raw)])
+    raw = bytearray(synth_jpeg(3))
+    i = raw.find(b"\xff\xda")
+    raw[i + 6] = 0x70                                     # SOS selects DC table 7
+    with pytest.raises(_abi.VipError):
+        pipeline.entropy_decode([bytes(raw)])

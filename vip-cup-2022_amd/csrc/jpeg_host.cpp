@@ -211,6 +211,10 @@ int parse(const uint8_t* d, size_t n, Parsed& P, bool need_scan) {
                 bool found = false;
                 for (int c = 0; c < P.ncomp; ++c)
                     if (P.comp[c].id == cid) {
+                        if ((s[2 + 2 * i] >> 4) > 3 || (s[2 + 2 * i] & 15) > 3) {
+                            vip_set_error("jpeg: SOS selects Huffman table %d/%d (0..3)", s[2 + 2 * i] >> 4, s[2 + 2 * i] & 15);
+                            return VIP_ERR_JPEG;
+                        }
                         P.comp[c].td = s[2 + 2 * i] >> 4;
                         P.comp[c].ta = s[2 + 2 * i] & 15;
                         sc.comp[i] = c;

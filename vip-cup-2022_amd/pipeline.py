@@ -28,6 +28,9 @@ def bicubic_table(device) -> torch.Tensor:
     return _TABLE_DEV[key]
 
 
+MAX_JPEG_PIXELS = int(os.environ.get("VIP_MAX_JPEG_PIXELS", str(64 << 20)))   # per image; the task's images are 200 x 200
+
+
 def entropy_decode(jpegs: Sequence[bytes], threads: int = 0):
     """Host stage: list of JPEG byte strings -> (desc array (ctypes), coef int16 numpy array).
     Raises VipError for streams outside the supported Huffman subset (SOF0/1/2, 8-bit, 1 or 3 components) (the reference raises too: TF)."""
@@ -44,6 +47,8 @@ def entropy_decode(jpegs: Sequence[bytes], threads: int = 0):
     need = C.c_size_t(0)
     for i in range(n):
         _abi.check(lib.vip_jpeg_probe_h(ptrs[i], lens[i], C.byref(tmp), C.byref(need)), "vip_jpeg_probe_h")
+        if tmp.width * tmp.height > MAX_JPEG_PIXELS:      # a corrupt header can claim 65535 x 65535: do not allocate for it
+            raise _abi.VipError(f"jpeg {i}: {tmp.width}x{tmp.height} exceeds VIP_MAX_JPEG_PIXELS={MAX_JPEG_PIXELS}")
         total += need.value
     coef = np.empty((max(total, 1),), dtype=np.int16)
     used = C.c_size_t(0)
