@@ -82,9 +82,10 @@ int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, const v
  * vip_conv2d_nhwc_f16 with a squeeze-excite gate folded into the activation load:
  *   y = epilogue( conv1x1( x[b,h,w,c] * gate[b,c] ) )
  * gate [B][2][Cin] f16: the split output of vip_se_gate_f16 / vip_gemm_split_f16 (hi = fp16(g), lo = fp16(g - hi)).
- * The operand is fma(x, hi, x * lo) in fp16 - one rounding per element, exactly what vip_scale_add_act3_f16 with two
- * scale planes would have written, so the result is bit-identical to scale-then-conv without the extra read+write of
- * the expanded tensor.  Replaces `Multiply()([inputs, se])` + the projection Conv2D of kecam se_module
+ * The operand is fma(x, hi, x * lo) in packed fp16 - one rounding per element.  vip_scale_add_act3_f16 with two scale
+ * planes followed by vip_conv2d_nhwc_f16 computes the same thing with x * (hi + lo) rounded from fp32: the two agree
+ * except where the inner rounding of x * lo tips the final one (rare, one ulp of one operand), and are bit-identical
+ * when lo = 0.  What the gated form saves is the read+write of the expanded tensor.  Replaces `Multiply()([inputs, se])` + the projection Conv2D of kecam se_module
  * (common_layers.py:328-332 with efficientnet_v2.py:97-101) and of gcvit/layers/feature.py:66-70,135-137.
  * Only 1x1 stride-1 ungrouped convolutions whose epilogue is (activation) or (residual [+ReLU]) are accepted
  * (VIP_ERR_UNSUPPORTED otherwise: scale with vip_scale_add_act_f16, then vip_conv2d_nhwc_f16).
