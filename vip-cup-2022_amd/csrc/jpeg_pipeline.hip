@@ -222,6 +222,25 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= outW || oy >= outH) return;
     const int h = sizes[2 * n], w = sizes[2 * n + 1];
+    f16* o = out + (((long)n * outH + oy) * outW + ox) * c_out;
+    auto store = [&](const float (&res)[3]) {
+        if (c_out == 8) {          // one 16-byte store per pixel
+            U4H8 v;
+            v.u = make_uint4(0, 0, 0, 0);
+            v.e[0] = (f16)res[0]; v.e[1] = (f16)res[1]; v.e[2] = (f16)res[2];
+            *reinterpret_cast<uint4*>(o) = v.u;
+        } else {
+            for (int c = 0; c < c_out; ++c) o[c] = (f16)(c < 3 ? res[c] : 0.f);
+        }
+    };
+    if (h == outH && w == outW) {
+        // same size (every 200x200 image at a 200x200 member): the legacy bicubic kernel's taps at scale 1 are exactly
+        // (0, 1, 0, 0) in both axes, so the general path below returns p / 255 bit for bit - read 3 bytes instead of 48
+        const uint8_t* p = rgb + ((long)n * maxH * maxW + (long)oy * maxW + ox) * 3;
+        const float res[3] = {__fdiv_rn((float)p[0], 255.f), __fdiv_rn((float)p[1], 255.f), __fdiv_rn((float)p[2], 255.f)};
+        store(res);
+        return;
+    }
     const Taps ty = bicubic_taps(oy, h, __fdiv_rn((float)h, (float)outH), table);
     const Taps tx = bicubic_taps(ox, w, __fdiv_rn((float)w, (float)outW), table);
     const uint8_t* img = rgb + (long)n * maxH * maxW * 3;
@@ -244,8 +263,7 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
         v = __fadd_rn(v, __fmul_rn(rowv[3], ty.w[3]));
         res[c] = __fdiv_rn(v, 255.f);
     }
-    f16* o = out + (((long)n * outH + oy) * outW + ox) * c_out;
-    for (int c = 0; c < c_out; ++c) o[c] = (f16)(c < 3 ? res[c] : 0.f);
+    store(res);
 }
 
 // TTA: flags bit0 hflip, bit1 vflip, bit2 gray (tf.image.rgb_to_grayscale weights 0.2989/0.5870/0.1140)
