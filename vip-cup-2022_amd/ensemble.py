@@ -95,14 +95,30 @@ def score_files(jpegs_for: Callable[[int, int], List[bytes]], n_images: int, mem
     counts = [shard_bounds(n_images, r, world)[1] - shard_bounds(n_images, r, world)[0] for r in range(world)]
     flags_all = tta_flags(n_images, tta, tta_seed) if tta > 1 else None
     chunks = []
-    for b0 in range(lo, hi, batch_size):
-        b1 = min(b0 + batch_size, hi)
-        raws = jpegs_for(b0, b1)
-        if flags_all is None:
-            chunks.append(scorer(raws, members) if scorer is not None else _score_batch(raws, members))
-        else:
-            fl = flags_all[:, b0:b1]
-            chunks.append(scorer(raws, members, fl) if scorer is not None else _score_batch(raws, members, fl))
+    starts = list(range(lo, hi, batch_size))
+
+    def host_stage(b0):
+        """file read + Huffman decode of one batch (C++ threads, the GIL is released inside the ctypes call)"""
+        raws = jpegs_for(b0, min(b0 + batch_size, hi))
+        if scorer is not None:
+            return raws
+        from . import pipeline
+        return pipeline.entropy_decode(raws)
+
+    # one batch of read-ahead: the host stage of batch i+1 runs while the GPU scores batch i (the reference gets the
+    # same overlap from tf.data's prefetch, dataset/dataset.py:101)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        nxt = pool.submit(host_stage, starts[0]) if starts else None
+        for i, b0 in enumerate(starts):
+            b1 = min(b0 + batch_size, hi)
+            staged = nxt.result()
+            nxt = pool.submit(host_stage, starts[i + 1]) if i + 1 < len(starts) else None
+            fl = None if flags_all is None else flags_all[:, b0:b1]
+            if scorer is not None:
+                chunks.append(scorer(staged, members) if fl is None else scorer(staged, members, fl))
+            else:
+                chunks.append(_score_batch(staged, members, fl))
     M = len(members)
     if chunks:
         local = torch.cat(chunks, dim=1)
@@ -128,11 +144,12 @@ class MemberStreams:
         self.assign: Optional[List[List[int]]] = None
 
     def _calibrate(self, members, inputs):
-        cost = []
+        """one serial, timed pass; its predictions ARE the first batch's result (nothing is computed twice)"""
+        cost, out = [], []
         for i, (spec, model) in enumerate(members):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            model.predict(inputs[spec.input_hw])
+            out.append(model.predict(inputs[spec.input_hw]))
             e1.record()
             e1.synchronize()
             cost.append(e0.elapsed_time(e1))
@@ -144,13 +161,14 @@ class MemberStreams:
             assign[j].append(i)
             load[j] += cost[i]
         self.assign = assign
+        return out
 
     def predict_all(self, members, inputs) -> list:
         """inputs: {input_hw: tensor} produced on the current stream.  Returns member.predict() per member."""
         if self.n <= 1 or len(members) <= 1:
             return [model.predict(inputs[spec.input_hw]) for spec, model in members]
         if self.assign is None or sum(len(a) for a in self.assign) != len(members):
-            self._calibrate(members, inputs)
+            return self._calibrate(members, inputs)
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
@@ -177,12 +195,13 @@ def default_streams() -> int:
 _MEMBER_STREAMS: Optional[MemberStreams] = None
 
 
-def _score_batch(raws: List[bytes], members, flags: Optional[np.ndarray] = None) -> torch.Tensor:
-    """decode once -> per member: resize to its resolution, predict, multi->binary.  Returns [M, n] (device).
+def _score_batch(staged, members, flags: Optional[np.ndarray] = None) -> torch.Tensor:
+    """``staged`` = ``pipeline.entropy_decode(raws)`` (or the raw JPEG byte strings).  Decode once -> per member: resize
+    to its resolution, predict, multi->binary.  Returns [M, n] (device).
     ``flags`` bool [tta, n, 3] (hflip, vflip, gray): one pass per row over augmented copies of the resized batch, mean
     over passes (the mean commutes with the multi->binary map 1 - p0)."""
     from . import pipeline
-    batch = pipeline.decode_jpegs(raws)
+    batch = pipeline.decode_entropy(staged) if isinstance(staged, tuple) else pipeline.decode_jpegs(staged)
     global _MEMBER_STREAMS
     if _MEMBER_STREAMS is None:
         _MEMBER_STREAMS = MemberStreams(default_streams())

@@ -79,8 +79,14 @@ class DecodedBatch:
 
 def decode_jpegs(jpegs: Sequence[bytes], device="cuda", threads: int = 0) -> DecodedBatch:
     """``tf.image.decode_jpeg(channels=3)`` for a batch (dataset/dataset.py:24-28)."""
-    desc, coef = entropy_decode(jpegs, threads)
-    n = len(jpegs)
+    return decode_entropy(entropy_decode(jpegs, threads), device)
+
+
+def decode_entropy(host_stage, device="cuda") -> DecodedBatch:
+    """Device half of ``decode_jpegs``: ``host_stage`` = ``entropy_decode(...)`` (which may have run on another thread
+    while the GPU was busy with the previous batch)."""
+    desc, coef = host_stage
+    n = len(desc)
     sizes_host = [(int(d.height), int(d.width)) for d in desc]
     maxH = max(h for h, _ in sizes_host)
     maxW = max(w for _, w in sizes_host)
