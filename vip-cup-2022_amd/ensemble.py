@@ -103,7 +103,7 @@ def score_files(jpegs_for: Callable[[int, int], List[bytes]], n_images: int, mem
         if scorer is not None:
             return raws
         from . import pipeline
-        return pipeline.entropy_decode(raws)
+        return pipeline.entropy_decode(raws, pinned=True)
 
     # one batch of read-ahead: the host stage of batch i+1 runs while the GPU scores batch i (the reference gets the
     # same overlap from tf.data's prefetch, dataset/dataset.py:101)

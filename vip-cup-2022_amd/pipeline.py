@@ -31,8 +31,10 @@ def bicubic_table(device) -> torch.Tensor:
 MAX_JPEG_PIXELS = int(os.environ.get("VIP_MAX_JPEG_PIXELS", str(64 << 20)))   # per image; the task's images are 200 x 200
 
 
-def entropy_decode(jpegs: Sequence[bytes], threads: int = 0):
-    """Host stage: list of JPEG byte strings -> (desc array (ctypes), coef int16 numpy array).
+def entropy_decode(jpegs: Sequence[bytes], threads: int = 0, pinned: bool = False):
+    """Host stage: list of JPEG byte strings -> (desc array (ctypes), coef int16 numpy array); with ``pinned`` the
+    coefficients come back as a page-locked torch tensor instead (torch caches such buffers), so that the H2D copy in
+    ``decode_entropy`` is asynchronous and runs at PCIe rate.
     Raises VipError for streams outside the supported Huffman subset (SOF0/1/2, 8-bit, 1 or 3 components) (the reference raises too: TF)."""
     lib = _abi.lib()
     n = len(jpegs)
@@ -50,12 +52,13 @@ def entropy_decode(jpegs: Sequence[bytes], threads: int = 0):
         if tmp.width * tmp.height > MAX_JPEG_PIXELS:      # a corrupt header can claim 65535 x 65535: do not allocate for it
             raise _abi.VipError(f"jpeg {i}: {tmp.width}x{tmp.height} exceeds VIP_MAX_JPEG_PIXELS={MAX_JPEG_PIXELS}")
         total += need.value
-    coef = np.empty((max(total, 1),), dtype=np.int16)
+    coef_t = torch.empty((max(total, 1),), dtype=torch.int16, pin_memory=True) if pinned else None
+    coef = coef_t.numpy() if pinned else np.empty((max(total, 1),), dtype=np.int16)
     used = C.c_size_t(0)
     st = lib.vip_jpeg_entropy_decode_h(ptrs, lens, n, desc, coef.ctypes.data_as(C.c_void_p), coef.size, C.byref(used),
                                        threads)
     _abi.check(st, "vip_jpeg_entropy_decode_h")
-    return desc, coef[:used.value]
+    return desc, (coef_t[:used.value] if pinned else coef[:used.value])
 
 
 class DecodedBatch:
@@ -91,10 +94,13 @@ def decode_entropy(host_stage, device="cuda") -> DecodedBatch:
     maxH = max(h for h, _ in sizes_host)
     maxW = max(w for _, w in sizes_host)
     max_blocks = max(sum(d.blocks_w[c] * d.blocks_h[c] for c in range(d.ncomp)) for d in desc)
-    coef_d = torch.from_numpy(coef).to(device, non_blocking=False)
+    if isinstance(coef, torch.Tensor):     # page-locked tensor from entropy_decode(pinned=True): asynchronous copy, and the
+        coef_d = coef.to(device, non_blocking=True)   # caching host allocator keeps the buffer until the copy has run
+    else:
+        coef_d = torch.from_numpy(coef).to(device)
     desc_bytes = np.frombuffer(bytes(desc), dtype=np.uint8)
     desc_d = torch.from_numpy(desc_bytes.copy()).to(device)
-    planes = torch.empty((coef.size,), dtype=torch.uint8, device=device)
+    planes = torch.empty((coef_d.numel(),), dtype=torch.uint8, device=device)
     rgb = torch.zeros((n, maxH, maxW, 3), dtype=torch.uint8, device=device)
     st = _abi.lib().vip_jpeg_idct_rgb_u8(_p(coef_d), _p(desc_d), n, max_blocks, _p(planes), _p(rgb), maxH, maxW,
                                          _stream())
