@@ -10,7 +10,8 @@ import torch
 from . import ops_ref as R
 
 # models/resnet_rs/block_args.py:1-44
-BLOCK_ARGS = {50: [(64, 3), (128, 4), (256, 6), (512, 3)], 101: [(64, 3), (128, 4), (256, 23), (512, 3)]}
+BLOCK_ARGS = {50: [(64, 3), (128, 4), (256, 6), (512, 3)], 101: [(64, 3), (128, 4), (256, 23), (512, 3)],
+              200: [(64, 3), (128, 24), (256, 36), (512, 3)]}          # block_args.py:2-25
 
 
 def _fixed_padding(x, k):
@@ -89,5 +90,5 @@ def forward_logits(p, x, **kw):
 
 def predict_logits(member, params, x):
     """Uniform entry used by tests / bench: member name -> logits."""
-    assert member == "resnet_rs50"
-    return forward_logits(params, x, depth=50)
+    assert member.startswith("resnet_rs") and int(member[9:]) in BLOCK_ARGS, member
+    return forward_logits(params, x, depth=int(member[9:]))

@@ -16,6 +16,9 @@ VIT = {  # name -> (embed_dim, nb_blocks, nb_heads, patch)   vit.py:470-481,530-
 }
 CONVNEXT = {  # name -> (embed_dim, nb_blocks, patch_size, first_down)   convnext.py:611-620,66-135
     "convnext_tiny_in22k": ((96, 192, 384, 768), (3, 3, 9, 3), 4, 1),
+    "convnext_small_in22k": ((96, 192, 384, 768), (3, 3, 27, 3), 4, 1),            # :623-632
+    "convnext_base_in22k": ((128, 256, 512, 1024), (3, 3, 27, 3), 4, 1),           # :635-644
+    "convnext_large_in22ft1k": ((192, 384, 768, 1536), (3, 3, 27, 3), 4, 1),       # :518-527
 }
 
 

@@ -48,6 +48,15 @@ def test_resnet_rs_tiny(report):
     assert frms < 5e-3 and fe < 3e-2
 
 
+def test_resnet_rs101_full(report):
+    """ResNet-RS-101 (block_args.py:8-13; the 200-layer variant of the earlier ensembles is the same code path)."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import resnet_rs
+    fe, frms, ze, z_ref = _run(resnet_rs.BLOCK_ARGS[101], 200, 3, report, "rs101", 1016)
+    assert frms < 4e-3
+    assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())
+
+
 def test_resnet_rs50_full(report):
     """Full ResNet-RS-50 at 200x200 on 8 synthetic images: logits vs the fp32 oracle."""
     fe, frms, ze, z_ref = _run(None, 200, 8, report, "rs50", 1006)

@@ -69,10 +69,10 @@ def test_vit(name, report):
     assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())
 
 
-def test_convnext_tiny(report):
+@pytest.mark.parametrize("name", ["convnext_tiny_in22k", "convnext_small_in22k", "convnext_base_in22k"])
+def test_convnext(name, report):
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops, tfimm_models as tm
-    name = "convnext_tiny_in22k"
     cfg = tm.CONVNEXT_CONFIGS[name]
     p = tm.convnext_synth_params(cfg, seed=1000)
     x = _images(2, 200).to(torch.float16).to(torch.float32)

@@ -29,7 +29,11 @@ def test_manifest_and_batch_table():
         assert [zoo.MEMBERS[key].input_hw] * 2 == dim
     # main.py:85  batch = 8 * NAME2BS.get(model_name, 16): no shipped member is in NAME2BS -> 128 for all of them
     assert not set(GOLD["main.py"]["NAME2BS"]) & {n for n, _, _ in GOLD["ckpts.json"]}
-    assert ensemble.REF_BATCH == 8 * 16
+    assert ensemble.REF_BATCH == 8 * 16 and ensemble.NAME2BS == GOLD["main.py"]["NAME2BS"]
+    assert ensemble.ref_batch("ResNetRS200-200x200") == 256 and ensemble.ref_batch("ResNetRS50-200x200") == 128
+    # the earlier ensembles' members that are re-configurations of graphs built here carry the manifest's naming scheme
+    for key in ("resnet_rs200", "convnext_base_in22k", "convnext_large_in22ft1k"):
+        assert zoo.MEMBERS[key].ckpt_name in GOLD["main.py"]["NAME2BS"], key
 
 
 def test_resnet_rs_block_args():
@@ -40,6 +44,7 @@ def test_resnet_rs_block_args():
     assert resnet_rs.BLOCK_ARGS == ref
     for d, v in resnet_rs_ref.BLOCK_ARGS.items():
         assert v == ref[d]
+    assert {50, 101, 200} <= set(resnet_rs_ref.BLOCK_ARGS)
 
 
 def test_gcvit_configs():
@@ -124,7 +129,11 @@ def test_tfimm_configs():
         cfg = tm.VIT_CONFIGS[name]
         assert (cfg.embed_dim, cfg.nb_blocks, cfg.nb_heads, cfg.patch_size) == (kw["embed_dim"], kw["nb_blocks"], kw["nb_heads"], kw["patch_size"])
         assert tfimm_ref.VIT[name] == (kw["embed_dim"], kw["nb_blocks"], kw["nb_heads"], kw["patch_size"])
-    kw = [c for c in GOLD["convnext.py"]["convnext_tiny_in22k"]["calls"] if c["func"] == "ConvNeXtConfig"][0]["kwargs"]
-    cfg = tm.CONVNEXT_CONFIGS["convnext_tiny_in22k"]
-    assert _tup(cfg.embed_dim) == _tup(kw["embed_dim"]) and _tup(cfg.nb_blocks) == _tup(kw["nb_blocks"])
-    assert _tup(tfimm_ref.CONVNEXT["convnext_tiny_in22k"][:2]) == (_tup(kw["embed_dim"]), _tup(kw["nb_blocks"]))
+    assert set(tm.CONVNEXT_CONFIGS) == set(GOLD["convnext.py"]) == set(tfimm_ref.CONVNEXT)
+    for name in GOLD["convnext.py"]:
+        kw = [c for c in GOLD["convnext.py"][name]["calls"] if c["func"] == "ConvNeXtConfig"][0]["kwargs"]
+        cfg = tm.CONVNEXT_CONFIGS[name]
+        assert kw["name"] == name and "first_down" not in kw and "patch_size" not in kw      # stride-2 4x4 stem (first_down = 1)
+        assert _tup(cfg.embed_dim) == _tup(kw["embed_dim"]) and _tup(cfg.nb_blocks) == _tup(kw["nb_blocks"])
+        assert (cfg.patch_size, cfg.first_down) == (4, 1)
+        assert _tup(tfimm_ref.CONVNEXT[name]) == (_tup(kw["embed_dim"]), _tup(kw["nb_blocks"]), 4, 1)

@@ -16,6 +16,17 @@ import torch
 
 THR = 0.487          # main.py:225
 REF_BATCH = 128      # 8 * NAME2BS.get(name, 16) for every shipped member (main.py:43-56,85)
+NAME2BS = {          # main.py:43-56: per-replica batch of the larger members of earlier ensembles (x 8 replicas, :85)
+    "convnext_large_384_in22ft1k-200x200": 16, "convnext_large_in22ft1k-200x200": 16, "convnext_base_384_in22ft1k-200x200": 32,
+    "HorNetBase-200x200": 32, "EfficientNetV2M-200x200": 64, "convnext_base_in22k-200x200": 32, "ECA_NFNetL2-200x200": 32,
+    "GCViTBase-224x224": 48, "ResNest200-200x200": 64, "EfficientNetV2L-200x200": 32, "ResNetRS200-200x200": 32,
+    "ResNet200D-200x200": 32,
+}
+
+
+def ref_batch(ckpt_name: str) -> int:
+    """the reference's batch size for a checkpoint directory name (main.py:85)"""
+    return 8 * NAME2BS.get(ckpt_name, 16)
 
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:

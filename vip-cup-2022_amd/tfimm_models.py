@@ -145,6 +145,10 @@ class ConvNeXtConfig:
 
 CONVNEXT_CONFIGS = {
     "convnext_tiny_in22k": ConvNeXtConfig("convnext_tiny_in22k"),  # convnext.py:611-620
+    # members of the earlier, larger ensembles (main.py:43-56 NAME2BS): same graph, wider / deeper
+    "convnext_small_in22k": ConvNeXtConfig("convnext_small_in22k", nb_blocks=(3, 3, 27, 3)),                          # :623-632
+    "convnext_base_in22k": ConvNeXtConfig("convnext_base_in22k", embed_dim=(128, 256, 512, 1024), nb_blocks=(3, 3, 27, 3)),    # :635-644
+    "convnext_large_in22ft1k": ConvNeXtConfig("convnext_large_in22ft1k", embed_dim=(192, 384, 768, 1536), nb_blocks=(3, 3, 27, 3)),  # :518-527
 }
 
 

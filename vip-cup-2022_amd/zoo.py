@@ -31,6 +31,20 @@ MEMBERS: Dict[str, MemberSpec] = {
     "resnet_rs50": MemberSpec("resnet_rs50", "ResNetRS50-200x200", 200, 1006,
                               lambda seed: resnet_rs.synth_params(50, seed),
                               lambda p: resnet_rs.ResNetRS50(p), "resnet_rs_ref", 3.790),
+    # members of the earlier, larger ensembles that are plain re-configurations of graphs built here (main.py:43-56)
+    "resnet_rs101": MemberSpec("resnet_rs101", "ResNetRS101-200x200", 200, 1016, lambda seed: resnet_rs.synth_params(101, seed),
+                               lambda p: resnet_rs.ResNetRS(p, depth=101), "resnet_rs_ref", 7.30),
+    "resnet_rs200": MemberSpec("resnet_rs200", "ResNetRS200-200x200", 200, 1026, lambda seed: resnet_rs.synth_params(200, seed),
+                               lambda p: resnet_rs.ResNetRS(p, depth=200), "resnet_rs_ref", 14.7),
+    "convnext_small_in22k": MemberSpec("convnext_small_in22k", "convnext_small_in22k-200x200", 200, 1010,
+                                       lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_small_in22k"], seed),
+                                       lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_small_in22k"]), "tfimm_ref", 25.9, "head/fc"),
+    "convnext_base_in22k": MemberSpec("convnext_base_in22k", "convnext_base_in22k-200x200", 200, 1020,
+                                      lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_base_in22k"], seed),
+                                      lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_base_in22k"]), "tfimm_ref", 45.8, "head/fc"),
+    "convnext_large_in22ft1k": MemberSpec("convnext_large_in22ft1k", "convnext_large_in22ft1k-200x200", 200, 1030,
+                                          lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"], seed),
+                                          lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"]), "tfimm_ref", 102.7, "head/fc"),
     "gcvit_tiny": MemberSpec("gcvit_tiny", "GCViTTiny-224x224", 224, 1002,
                              lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_tiny"], seed),
                              lambda p: gcvit.GCViTTiny(p), "gcvit_ref", 4.760, "head"),
