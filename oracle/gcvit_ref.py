@@ -14,6 +14,11 @@ NAME2CONFIG = {
     "gcvit_xxtiny": dict(window_size=(7, 7, 14, 7), dim=64, depths=(2, 2, 6, 2), num_heads=(2, 4, 8, 16), mlp_ratio=3.0),
     "gcvit_xtiny": dict(window_size=(7, 7, 14, 7), dim=64, depths=(3, 4, 6, 5), num_heads=(2, 4, 8, 16), mlp_ratio=3.0),
     "gcvit_tiny": dict(window_size=(7, 7, 14, 7), dim=64, depths=(3, 4, 19, 5), num_heads=(2, 4, 8, 16), mlp_ratio=3.0),
+    # models/gcvit.py:29-42: the two variants with a (trained) per-channel layer scale on both residual branches
+    "gcvit_small": dict(window_size=(7, 7, 14, 7), dim=96, depths=(3, 4, 19, 5), num_heads=(3, 6, 12, 24), mlp_ratio=2.0,
+                        layer_scale=1e-5),
+    "gcvit_base": dict(window_size=(7, 7, 14, 7), dim=128, depths=(3, 4, 19, 5), num_heads=(4, 8, 16, 32), mlp_ratio=2.0,
+                       layer_scale=1e-5),
 }
 KEEP_DIMS = [(False, False, False), (False, False), (True,), (True,)]  # models/gcvit.py:71
 LN_EPS = 1e-5
@@ -99,14 +104,17 @@ def mlp(p, name, x):
 
 
 def block(p, name, x, q_global, ws, heads):
-    """GCViTBlock.call (block.py:60-81); layer_scale is None for Tiny so gamma1 = gamma2 = 1."""
+    """GCViTBlock.call (block.py:60-81); gamma1 / gamma2 exist only when the config has a layer_scale (:41-56)."""
     B, H, W, C = x.shape
     y = _ln(p, f"{name}/norm1", x)
     y = R.window_partition(y, ws).reshape(-1, ws * ws, C)
     y = window_attention(p, f"{name}/attn", y, q_global, ws, heads)
     y = R.window_reverse(y, ws, H, W, C)
-    x = x + y
-    return x + mlp(p, f"{name}/mlp", _ln(p, f"{name}/norm2", x))
+    g1 = p.get(f"{name}/gamma1")
+    g2 = p.get(f"{name}/gamma2")
+    x = x + (y if g1 is None else y * g1)                                  # :79
+    m = mlp(p, f"{name}/mlp", _ln(p, f"{name}/norm2", x))
+    return x + (m if g2 is None else g2 * m)                               # :80
 
 
 def level(p, name, x, depth, heads, ws, keep_dims, downsample):

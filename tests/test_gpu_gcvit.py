@@ -47,6 +47,16 @@ def test_gcvit_tiny_full(report):
     assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())
 
 
+@pytest.mark.parametrize("name", ["gcvit_small", "gcvit_base"])
+def test_gcvit_layer_scale_variants(name, report):
+    """gcvit_small / gcvit_base (models/gcvit.py:29-42): dim 96 / 128, mlp_ratio 2, heads of 32 channels, and the
+    per-channel layer scale gamma1 / gamma2 on both residual branches (block.py:41-56,79-80) - at depths (2,2,2,2)."""
+    cfg = dict(ref.NAME2CONFIG[name], depths=(2, 2, 2, 2))
+    frms, ze, z_ref = _run(cfg, 2, report, f"{name} d2222", seed=1032)
+    assert frms < 5e-3
+    assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())
+
+
 def test_gcvit_fit_window_padding(report):
     """200x200 input: the level feature maps (50, 25, 13, 7) are not multiples of the windows (7, 7, 14, 7), so
     FitWindow pads them (feature.py:240-249) and the level crops back (level.py:61)."""

@@ -32,7 +32,7 @@ def test_manifest_and_batch_table():
     assert ensemble.REF_BATCH == 8 * 16 and ensemble.NAME2BS == GOLD["main.py"]["NAME2BS"]
     assert ensemble.ref_batch("ResNetRS200-200x200") == 256 and ensemble.ref_batch("ResNetRS50-200x200") == 128
     # the earlier ensembles' members that are re-configurations of graphs built here carry the manifest's naming scheme
-    for key in ("resnet_rs200", "convnext_base_in22k", "convnext_large_in22ft1k"):
+    for key in ("resnet_rs200", "convnext_base_in22k", "convnext_large_in22ft1k", "gcvit_base"):
         assert zoo.MEMBERS[key].ckpt_name in GOLD["main.py"]["NAME2BS"], key
 
 
@@ -56,8 +56,8 @@ def test_gcvit_configs():
         for name, cfg in table.items():
             for k, v in cfg.items():
                 assert _tup(ref[name][k]) == _tup(v), (name, k)
-            assert "layer_scale" not in ref[name], name               # the built variants carry no layer scale
-    assert "gcvit_tiny" in gcvit.NAME2CONFIG and "gcvit_tiny" in gcvit_ref.NAME2CONFIG
+            assert ("layer_scale" in ref[name]) == ("layer_scale" in cfg), name
+    assert set(gcvit.NAME2CONFIG) == set(gcvit_ref.NAME2CONFIG) == set(ref)
 
 
 def test_efficientnet_tables():

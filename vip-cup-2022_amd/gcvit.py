@@ -17,6 +17,10 @@ NAME2CONFIG = {
     "gcvit_xxtiny": dict(window_size=(7, 7, 14, 7), dim=64, depths=(2, 2, 6, 2), num_heads=(2, 4, 8, 16), mlp_ratio=3.0),
     "gcvit_xtiny": dict(window_size=(7, 7, 14, 7), dim=64, depths=(3, 4, 6, 5), num_heads=(2, 4, 8, 16), mlp_ratio=3.0),
     "gcvit_tiny": dict(window_size=(7, 7, 14, 7), dim=64, depths=(3, 4, 19, 5), num_heads=(2, 4, 8, 16), mlp_ratio=3.0),
+    "gcvit_small": dict(window_size=(7, 7, 14, 7), dim=96, depths=(3, 4, 19, 5), num_heads=(3, 6, 12, 24), mlp_ratio=2.0,
+                        layer_scale=1e-5),
+    "gcvit_base": dict(window_size=(7, 7, 14, 7), dim=128, depths=(3, 4, 19, 5), num_heads=(4, 8, 16, 32), mlp_ratio=2.0,
+                       layer_scale=1e-5),
 }
 KEEP_DIMS = [(False, False, False), (False, False), (True,), (True,)]  # models/gcvit.py:71
 LN_EPS = 1e-5
@@ -57,6 +61,9 @@ def synth_params(cfg: Dict, seed: int = 1002, classes: int = 1) -> Dict[str, tor
             g.ln(f"{b}/norm2", c)
             g.dense(f"{b}/mlp/fc1", c, int(c * cfg["mlp_ratio"]), gain=2.0)
             g.dense(f"{b}/mlp/fc2", int(c * cfg["mlp_ratio"]), c, gain=0.25)
+            if cfg.get("layer_scale") is not None:      # trained values (the 1e-5 init would mute both branches)
+                g.raw(f"{b}/gamma1", g._u((c,), 0.5, 1.5))
+                g.raw(f"{b}/gamma2", g._u((c,), 0.5, 1.5))
         if i < n - 1:
             reduce_size(f"levels/{i}/downsample", c, False)
             c *= 2
@@ -112,10 +119,17 @@ class _Block:
         self.n1 = _LN(p, f"{name}/norm1", dev)
         self.n2 = _LN(p, f"{name}/norm2", dev)
         self.qkv = ops.make_dense_weight(p[f"{name}/attn/qkv/kernel"], p[f"{name}/attn/qkv/bias"], dev)
-        self.proj = ops.make_dense_weight(p[f"{name}/attn/proj/kernel"], p[f"{name}/attn/proj/bias"], dev)
+        # layer scale (block.py:41-56,79-80): a per-channel gain on each residual branch = a gain on the rows of the
+        # branch's last Dense, folded here
+        g1 = p.get(f"{name}/gamma1")
+        g2 = p.get(f"{name}/gamma2")
+
+        def scaled(kernel, bias, g):
+            return (kernel, bias) if g is None else (kernel * g[None, :], bias * g)
+        self.proj = ops.make_dense_weight(*scaled(p[f"{name}/attn/proj/kernel"], p[f"{name}/attn/proj/bias"], g1), dev)
         self.table = p[f"{name}/attn/relative_position_bias_table"].to(dev, torch.float32).contiguous()
         self.fc1 = ops.make_dense_weight(p[f"{name}/mlp/fc1/kernel"], p[f"{name}/mlp/fc1/bias"], dev)
-        self.fc2 = ops.make_dense_weight(p[f"{name}/mlp/fc2/kernel"], p[f"{name}/mlp/fc2/bias"], dev)
+        self.fc2 = ops.make_dense_weight(*scaled(p[f"{name}/mlp/fc2/kernel"], p[f"{name}/mlp/fc2/bias"], g2), dev)
 
     def __call__(self, x, q_global):
         C = x.shape[-1]
@@ -129,7 +143,7 @@ class _Block:
 
 class GCViT:
     def __init__(self, params: Dict[str, torch.Tensor], window_size, dim, depths, num_heads, mlp_ratio=3.0,
-                 classes: int = 1, device="cuda"):
+                 layer_scale=None, classes: int = 1, device="cuda"):
         p, dev = params, device
         self.cfg = dict(window_size=window_size, dim=dim, depths=depths, num_heads=num_heads, mlp_ratio=mlp_ratio)
         self.classes = classes

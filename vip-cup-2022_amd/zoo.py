@@ -45,6 +45,9 @@ MEMBERS: Dict[str, MemberSpec] = {
     "convnext_large_in22ft1k": MemberSpec("convnext_large_in22ft1k", "convnext_large_in22ft1k-200x200", 200, 1030,
                                           lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"], seed),
                                           lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"]), "tfimm_ref", 102.7, "head/fc"),
+    "gcvit_base": MemberSpec("gcvit_base", "GCViTBase-224x224", 224, 1022,
+                             lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_base"], seed),
+                             lambda p: gcvit.GCViT(p, **gcvit.NAME2CONFIG["gcvit_base"]), "gcvit_ref", 14.3, "head"),
     "gcvit_tiny": MemberSpec("gcvit_tiny", "GCViTTiny-224x224", 224, 1002,
                              lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_tiny"], seed),
                              lambda p: gcvit.GCViTTiny(p), "gcvit_ref", 4.760, "head"),
