@@ -125,6 +125,15 @@ EFFNET = {
                              depthes=[int(math.ceil(ii * 1.8)) for ii in [1, 2, 2, 3, 3, 4, 1]],
                              strides=[1, 2, 2, 2, 1, 2, 1], se_ratios=[0.25] * 7, kernel_sizes=[3, 3, 5, 3, 5, 5, 3],
                              first_conv_filter=32 * 1.4, output_conv_filter=1280 * 1.4, is_torch_mode=False),
+    # efficientnet_v2.py:300-325 (members of the earlier ensembles): TF-SAME padding / BN eps 1e-3 like every non-"T" variant
+    "EfficientNetV2M": dict(expands=[1, 4, 4, 4, 6, 6, 6], out_channels=[24, 48, 80, 160, 176, 304, 512],
+                            depthes=[3, 5, 5, 7, 14, 18, 5], strides=[1, 2, 2, 2, 1, 2, 1],
+                            se_ratios=[0, 0, 0, 0.25, 0.25, 0.25, 0.25], kernel_sizes=[3] * 7, first_conv_filter=24,
+                            output_conv_filter=1280, is_torch_mode=False),
+    "EfficientNetV2L": dict(expands=[1, 4, 4, 4, 6, 6, 6], out_channels=[32, 64, 96, 192, 224, 384, 640],
+                            depthes=[4, 7, 7, 10, 19, 25, 7], strides=[1, 2, 2, 2, 1, 2, 1],
+                            se_ratios=[0, 0, 0, 0.25, 0.25, 0.25, 0.25], kernel_sizes=[3] * 7, first_conv_filter=32,
+                            output_conv_filter=1280, is_torch_mode=False),
 }
 
 
@@ -240,13 +249,18 @@ def nfnet_features(p, x, num_blocks=(1, 2, 6, 3), out_channels=(256, 512, 1536, 
 
 # ------------------------------------------------------------------------------------------------
 ALIASES = {"resnest50": "ResNest50", "efficientnet_v2t": "EfficientNetV2T", "efficientnet_v1b4": "EfficientNetV1B4",
-           "eca_nfnet_l0": "ECA_NFNetL0"}
+           "eca_nfnet_l0": "ECA_NFNetL0", "resnest200": "ResNest200", "eca_nfnet_l2": "ECA_NFNetL2",
+           "efficientnet_v2m": "EfficientNetV2M", "efficientnet_v2l": "EfficientNetV2L"}
 
 
 def features(member, p, x, collect=None):
     member = ALIASES.get(member, member)
     if member == "ResNest50":
         return resnest_features(p, x, collect=collect)
+    if member == "ResNest200":                      # resnest.py:84-85
+        return resnest_features(p, x, num_blocks=(3, 24, 36, 3), stem_width=128, collect=collect)
+    if member == "ECA_NFNetL2":                     # nfnets.py:329-332; num_features_factor: NormFreeNet's default 2
+        return nfnet_features(p, x, num_blocks=(3, 6, 18, 9), num_features_factor=2, collect=collect)
     if member in EFFNET:
         return effnet_features(p, x, member, collect=collect)
     if member == "ECA_NFNetL0":

@@ -53,3 +53,61 @@ def test_kecam_member(key, report):
     report(f"[{key}] logit max_abs_err={ze:.3e} logit mean={z_ref.mean().item():.3f} std={z_ref.std().item():.3f}")
     assert worst < 6e-3
     assert ze < 6e-3 * max(1.0, z_ref.abs().max().item())   # raw synthetic head; 38-block MBConv net: see DESIGN.md §4
+
+
+def _compare(report, tag, ca, cb, z, z_ref):
+    assert len(ca) == len(cb)
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(ca, cb)):
+        b = b.float().cpu()
+        assert a.shape == b.shape, (i, a.shape, b.shape)
+        worst = max(worst, ((a - b) ** 2).mean().sqrt().item() / a.pow(2).mean().sqrt().item())
+    ze = (z - z_ref).abs().max().item()
+    report(f"[{tag}] worst stage rel_rms_err {worst:.3e} | logit max_abs_err={ze:.3e} logit mean={z_ref.mean().item():.3f}")
+    assert worst < 6e-3
+    assert ze < 6e-3 * max(1.0, z_ref.abs().max().item())
+
+
+def test_kecam_legacy_configs_reduced_depth(report):
+    """The larger members of the reference's earlier ensembles (main.py:43-56) that are re-configurations of graphs built
+    here - ResNest200 (stem 128), ECA_NFNetL2 (features x2), EfficientNetV2M (7 stages, TF-SAME, SE from stage 3 on) - at
+    reduced depth: every config-specific path once, without the activation growth that seeded weights give 60+ blocks."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import kecam_models as km, ops
+    x = _images(2, 200).to(torch.float16).to(torch.float32)
+    xd = ops.to_device_nhwc8(x)
+
+    cfg = dict(km.RESNEST200, num_blocks=(1, 2, 2, 1))
+    p = km.resnest_synth_params(1021, cfg=cfg)
+    ca, cb = [], []
+    with torch.no_grad():
+        f = ref.resnest_features(p, x, num_blocks=cfg["num_blocks"], stem_width=cfg["stem_width"], collect=ca)
+        z_ref = ref.R.dense(ref.R.global_avgpool(f), p["predictions/kernel"], p["predictions/bias"])
+    m = km.ResNest(p, cfg=cfg)
+    m.features(xd, collect=cb)
+    _compare(report, "ResNest200 d1221", ca, cb, m.logits(xd).cpu(), z_ref)
+
+    cfg = dict(km.NFNET_L2, num_blocks=(1, 2, 2, 1))
+    p = km.nfnet_synth_params(1025, cfg=cfg)
+    ca, cb = [], []
+    with torch.no_grad():
+        f = ref.nfnet_features(p, x, num_blocks=cfg["num_blocks"], num_features_factor=cfg["num_features_factor"], collect=ca)
+        z_ref = ref.R.dense(ref.R.global_avgpool(f), p["predictions/kernel"], p["predictions/bias"])
+    m = km.NormFreeNet(p, cfg=cfg)
+    m.features(xd, collect=cb)
+    _compare(report, "ECA_NFNetL2 d1221", ca, cb, m.logits(xd).cpu(), z_ref)
+
+    name = "EfficientNetV2M_d"
+    small = dict(km.EFFNET["EfficientNetV2M"], depthes=[1, 2, 2, 2, 2, 2, 1])
+    km.EFFNET[name] = ref.EFFNET[name] = small
+    try:
+        p = km.effnet_synth_params(name, 1023)
+        ca, cb = [], []
+        with torch.no_grad():
+            z_ref = ref.predict_logits(name, p, x)
+            ref.features(name, p, x, collect=ca)
+        m = km.EfficientNet(p, name)
+        m.features(xd, collect=cb)
+        _compare(report, "EfficientNetV2M d1222221", ca, cb, m.logits(xd).cpu(), z_ref)
+    finally:
+        del km.EFFNET[name], ref.EFFNET[name]

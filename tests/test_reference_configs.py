@@ -32,7 +32,8 @@ def test_manifest_and_batch_table():
     assert ensemble.REF_BATCH == 8 * 16 and ensemble.NAME2BS == GOLD["main.py"]["NAME2BS"]
     assert ensemble.ref_batch("ResNetRS200-200x200") == 256 and ensemble.ref_batch("ResNetRS50-200x200") == 128
     # the earlier ensembles' members that are re-configurations of graphs built here carry the manifest's naming scheme
-    for key in ("resnet_rs200", "convnext_base_in22k", "convnext_large_in22ft1k", "gcvit_base"):
+    for key in ("resnet_rs200", "convnext_base_in22k", "convnext_large_in22ft1k", "gcvit_base", "resnest200", "eca_nfnet_l2",
+                "efficientnet_v2m", "efficientnet_v2l"):
         assert zoo.MEMBERS[key].ckpt_name in GOLD["main.py"]["NAME2BS"], key
 
 
@@ -89,6 +90,15 @@ def test_efficientnet_tables():
                 else:
                     assert got == pytest.approx(v), (name, k)
     assert base2["activation"] == "swish" and v1["EfficientNetV1B4"]["defaults"]["first_strides"] == 2
+    for name in ("EfficientNetV2M", "EfficientNetV2L"):                 # efficientnet_v2.py:300-325
+        a = v2[name]["assigns"]
+        pops = {c["args"][0]: c["args"][1] for c in v2[name]["calls"] if c["func"] == "pop" and len(c["args"]) == 2}
+        for table in (km.EFFNET, kecam_ref.EFFNET):
+            t = table[name]
+            for k in ("out_channels", "depthes", "expands", "strides", "se_ratios"):
+                assert list(t[k]) == a[k], (name, k)
+            assert t["kernel_sizes"] == [base2["kernel_sizes"]] * 7 and t["is_torch_mode"] == base2["is_torch_mode"]
+            assert (t["first_conv_filter"], t["output_conv_filter"]) == (pops["first_conv_filter"], pops["output_conv_filter"])
 
 
 def test_resnest_and_nfnet_tables():
@@ -117,6 +127,11 @@ def test_resnest_and_nfnet_tables():
     for k in ("num_blocks", "out_channels", "strides"):
         assert _tup(sig[k].default) == _tup(want[k]), k
     assert l0["attn_type"] == "eca" and nf["ECA_NFNetL0"]["defaults"]["activation"] == "swish"
+    l2 = nf["ECA_NFNetL2"]["assigns"]                                   # nfnets.py:329-332: no factor given -> NormFreeNet's 2
+    assert _tup(km.NFNET_L2["num_blocks"]) == _tup(l2["num_blocks"]) and "num_features_factor" not in l2
+    assert km.NFNET_L2["num_features_factor"] == base["num_features_factor"] and l2["attn_type"] == "eca"
+    c200 = [c for c in rs["ResNest200"]["calls"] if c["func"] == "ResNest"][0]["kwargs"]
+    assert _tup(km.RESNEST200["num_blocks"]) == _tup(c200["num_blocks"]) and km.RESNEST200["stem_width"] == c200["stem_width"]
     assert light["torch_padding"] is True and light["gamma_in_act"] is False and light["use_zero_init_gain"] is False
 
 

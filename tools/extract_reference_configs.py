@@ -77,11 +77,13 @@ out = {
     "ckpts.json": json.load(open(os.path.join(REF, "ckpts", "ckpts.json"))) if os.path.exists(os.path.join(REF, "ckpts", "ckpts.json")) else None,
     "resnet_rs/block_args.py": module_constants("models/resnet_rs/block_args.py", {"BLOCK_ARGS"}),
     "gcvit/models/gcvit.py": module_constants("models/gcvit/models/gcvit.py", {"NAME2CONFIG"}),
-    "efficientnet_v2.py": {n: function_literals(K + "efficientnet/efficientnet_v2.py", n) for n in ("EfficientNetV2", "EfficientNetV2T")},
+    "efficientnet_v2.py": {n: function_literals(K + "efficientnet/efficientnet_v2.py", n)
+                           for n in ("EfficientNetV2", "EfficientNetV2T", "EfficientNetV2M", "EfficientNetV2L")},
     "efficientnet_v1.py": {n: function_literals(K + "efficientnet/efficientnet_v1.py", n)
                            for n in ("get_expanded_width_depth", "EfficientNetV1", "EfficientNetV1B4")},
-    "resnest.py": {n: function_literals(K + "resnest/resnest.py", n) for n in ("ResNest", "ResNest50")},
-    "nfnets.py": {n: function_literals(K + "nfnets/nfnets.py", n) for n in ("NormFreeNet", "NormFreeNet_Light", "ECA_NFNetL0")},
+    "resnest.py": {n: function_literals(K + "resnest/resnest.py", n) for n in ("ResNest", "ResNest50", "ResNest200")},
+    "nfnets.py": {n: function_literals(K + "nfnets/nfnets.py", n)
+                  for n in ("NormFreeNet", "NormFreeNet_Light", "ECA_NFNetL0", "ECA_NFNetL2")},
     "aotnet.py": {n: function_literals(K + "aotnet/aotnet.py", n) for n in ("AotNet",)},
     "vit.py": {n: function_literals(T + "vit.py", n) for n in ("vit_tiny_patch16_224", "vit_small_patch16_224", "vit_base_patch16_224")},
     "convnext.py": {n: function_literals(T + "convnext.py", n)

@@ -70,6 +70,7 @@ class _Base:
 # ResNest50
 # ------------------------------------------------------------------------------------------------
 RESNEST50 = dict(num_blocks=(3, 4, 6, 3), out_channels=(256, 512, 1024, 2048), strides=(1, 2, 2, 2), stem_width=64)
+RESNEST200 = dict(RESNEST50, num_blocks=(3, 24, 36, 3), stem_width=128)        # resnest.py:84-85
 
 
 def resnest_synth_params(seed: int, classes: int = 1, cfg=RESNEST50) -> Dict[str, torch.Tensor]:
@@ -177,6 +178,15 @@ EFFNET = {
                              depthes=[int(math.ceil(ii * 1.8)) for ii in [1, 2, 2, 3, 3, 4, 1]],
                              strides=[1, 2, 2, 2, 1, 2, 1], se_ratios=[0.25] * 7, kernel_sizes=[3, 3, 5, 3, 5, 5, 3],
                              first_conv_filter=32 * 1.4, output_conv_filter=1280 * 1.4, is_torch_mode=False),
+    # efficientnet_v2.py:300-325 (members of the earlier ensembles): TF-SAME padding / BN eps 1e-3 like every non-"T" variant
+    "EfficientNetV2M": dict(expands=[1, 4, 4, 4, 6, 6, 6], out_channels=[24, 48, 80, 160, 176, 304, 512],
+                            depthes=[3, 5, 5, 7, 14, 18, 5], strides=[1, 2, 2, 2, 1, 2, 1],
+                            se_ratios=[0, 0, 0, 0.25, 0.25, 0.25, 0.25], kernel_sizes=[3] * 7, first_conv_filter=24,
+                            output_conv_filter=1280, is_torch_mode=False),
+    "EfficientNetV2L": dict(expands=[1, 4, 4, 4, 6, 6, 6], out_channels=[32, 64, 96, 192, 224, 384, 640],
+                            depthes=[4, 7, 7, 10, 19, 25, 7], strides=[1, 2, 2, 2, 1, 2, 1],
+                            se_ratios=[0, 0, 0, 0.25, 0.25, 0.25, 0.25], kernel_sizes=[3] * 7, first_conv_filter=32,
+                            output_conv_filter=1280, is_torch_mode=False),
 }
 
 
@@ -296,6 +306,7 @@ class EfficientNet(_Base):
 # ------------------------------------------------------------------------------------------------
 NFNET_L0 = dict(num_blocks=(1, 2, 6, 3), out_channels=(256, 512, 1536, 1536), strides=(1, 2, 2, 2), stem_width=128,
                 alpha=0.2, channel_ratio=0.25, group_size=64, num_features_factor=1.5)
+NFNET_L2 = dict(NFNET_L0, num_blocks=(3, 6, 18, 9), num_features_factor=2)     # nfnets.py:329-332 (NormFreeNet default factor :210)
 SWISH_GAMMA = 1.7881293296813965  # nfnets.py:34
 
 

@@ -45,6 +45,16 @@ MEMBERS: Dict[str, MemberSpec] = {
     "convnext_large_in22ft1k": MemberSpec("convnext_large_in22ft1k", "convnext_large_in22ft1k-200x200", 200, 1030,
                                           lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"], seed),
                                           lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"]), "tfimm_ref", 102.7, "head/fc"),
+    "resnest200": MemberSpec("resnest200", "ResNest200-200x200", 200, 1021, lambda seed: km.resnest_synth_params(seed, cfg=km.RESNEST200),
+                             lambda p: km.ResNest(p, cfg=km.RESNEST200), "kecam_ref", 29.0),
+    "eca_nfnet_l2": MemberSpec("eca_nfnet_l2", "ECA_NFNetL2-200x200", 200, 1025, lambda seed: km.nfnet_synth_params(seed, cfg=km.NFNET_L2),
+                               lambda p: km.NormFreeNet(p, cfg=km.NFNET_L2), "kecam_ref", 10.6),
+    "efficientnet_v2m": MemberSpec("efficientnet_v2m", "EfficientNetV2M-200x200", 200, 1023,
+                                   lambda seed: km.effnet_synth_params("EfficientNetV2M", seed),
+                                   lambda p: km.EfficientNet(p, "EfficientNetV2M"), "kecam_ref", 4.3),
+    "efficientnet_v2l": MemberSpec("efficientnet_v2l", "EfficientNetV2L-200x200", 200, 1024,
+                                   lambda seed: km.effnet_synth_params("EfficientNetV2L", seed),
+                                   lambda p: km.EfficientNet(p, "EfficientNetV2L"), "kecam_ref", 9.8),
     "gcvit_base": MemberSpec("gcvit_base", "GCViTBase-224x224", 224, 1022,
                              lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_base"], seed),
                              lambda p: gcvit.GCViT(p, **gcvit.NAME2CONFIG["gcvit_base"]), "gcvit_ref", 14.3, "head"),
