@@ -84,7 +84,7 @@ def split_attention_conv2d(p, name, x, filters, strides, eps, groups=2, act="rel
 
 
 def resnest_features(p, x, num_blocks=(3, 4, 6, 3), out_channels=(256, 512, 1024, 2048), strides=(1, 2, 2, 2),
-                     stem_width=64, eps=1e-5, first_strides=2, collect=None):
+                     stem_width=64, eps=1e-5, first_strides=2, collect=None, attn="sa"):
     """AotNet (aotnet/aotnet.py:284-377) specialised by ResNest (resnest.py:69-77)"""
     act = "relu"
     # deep_stem (:235-242) + stem_bn + pad/MaxPool (:326-330)
@@ -105,7 +105,10 @@ def resnest_features(p, x, num_blocks=(3, 4, 6, 3), out_channels=(256, 512, 1024
                 sc = x
             hid = int(oc * 0.25)
             d = _bn(p, f"{n}deep_1_", _conv(p, f"{n}deep_1_", x, 1), eps, act)       # deep_branch (:118-134)
-            d = split_attention_conv2d(p, f"{n}deep_2_sa_", d, hid, s, eps)
+            if attn == "sa":
+                d = split_attention_conv2d(p, f"{n}deep_2_sa_", d, hid, s, eps)
+            else:       # ResNetD (resnet_deep.py:13-16): attn_types None -> conv3x3 with the stride (aotnet.py:78-81) + BN + act (:89-91)
+                d = _bn(p, f"{n}deep_2_", _conv(p, f"{n}deep_2_", d, 3, s, "same"), eps, act)
             d = _conv(p, f"{n}deep_3_", d, 1)
             d = _bn(p, f"{n}3_", d, eps)                                              # zero_gamma BN (:187)
             x = R.act(sc + d, act)
@@ -250,13 +253,15 @@ def nfnet_features(p, x, num_blocks=(1, 2, 6, 3), out_channels=(256, 512, 1536, 
 # ------------------------------------------------------------------------------------------------
 ALIASES = {"resnest50": "ResNest50", "efficientnet_v2t": "EfficientNetV2T", "efficientnet_v1b4": "EfficientNetV1B4",
            "eca_nfnet_l0": "ECA_NFNetL0", "resnest200": "ResNest200", "eca_nfnet_l2": "ECA_NFNetL2",
-           "efficientnet_v2m": "EfficientNetV2M", "efficientnet_v2l": "EfficientNetV2L"}
+           "efficientnet_v2m": "EfficientNetV2M", "efficientnet_v2l": "EfficientNetV2L", "resnet200d": "ResNet200D"}
 
 
 def features(member, p, x, collect=None):
     member = ALIASES.get(member, member)
     if member == "ResNest50":
         return resnest_features(p, x, collect=collect)
+    if member == "ResNet200D":                      # resnet_deep.py:34-36
+        return resnest_features(p, x, num_blocks=(3, 24, 36, 3), attn=None, collect=collect)
     if member == "ResNest200":                      # resnest.py:84-85
         return resnest_features(p, x, num_blocks=(3, 24, 36, 3), stem_width=128, collect=collect)
     if member == "ECA_NFNetL2":                     # nfnets.py:329-332; num_features_factor: NormFreeNet's default 2

@@ -87,6 +87,16 @@ def test_kecam_legacy_configs_reduced_depth(report):
     m.features(xd, collect=cb)
     _compare(report, "ResNest200 d1221", ca, cb, m.logits(xd).cpu(), z_ref)
 
+    cfg = dict(km.RESNET200D, num_blocks=(1, 2, 2, 1))
+    p = km.resnest_synth_params(1027, cfg=cfg)
+    ca, cb = [], []
+    with torch.no_grad():
+        f = ref.resnest_features(p, x, num_blocks=cfg["num_blocks"], attn=None, collect=ca)
+        z_ref = ref.R.dense(ref.R.global_avgpool(f), p["predictions/kernel"], p["predictions/bias"])
+    m = km.ResNest(p, cfg=cfg)
+    m.features(xd, collect=cb)
+    _compare(report, "ResNet200D d1221", ca, cb, m.logits(xd).cpu(), z_ref)
+
     cfg = dict(km.NFNET_L2, num_blocks=(1, 2, 2, 1))
     p = km.nfnet_synth_params(1025, cfg=cfg)
     ca, cb = [], []

@@ -32,7 +32,7 @@ def test_manifest_and_batch_table():
     assert ensemble.REF_BATCH == 8 * 16 and ensemble.NAME2BS == GOLD["main.py"]["NAME2BS"]
     assert ensemble.ref_batch("ResNetRS200-200x200") == 256 and ensemble.ref_batch("ResNetRS50-200x200") == 128
     # the earlier ensembles' members that are re-configurations of graphs built here carry the manifest's naming scheme
-    for key in ("resnet_rs200", "convnext_base_in22k", "convnext_large_in22ft1k", "gcvit_base", "resnest200", "eca_nfnet_l2",
+    for key in ("resnet_rs200", "convnext_base_in22k", "convnext_large_in22ft1k", "gcvit_base", "resnest200", "eca_nfnet_l2", "resnet200d",
                 "efficientnet_v2m", "efficientnet_v2l"):
         assert zoo.MEMBERS[key].ckpt_name in GOLD["main.py"]["NAME2BS"], key
 
@@ -130,6 +130,10 @@ def test_resnest_and_nfnet_tables():
     l2 = nf["ECA_NFNetL2"]["assigns"]                                   # nfnets.py:329-332: no factor given -> NormFreeNet's 2
     assert _tup(km.NFNET_L2["num_blocks"]) == _tup(l2["num_blocks"]) and "num_features_factor" not in l2
     assert km.NFNET_L2["num_features_factor"] == base["num_features_factor"] and l2["attn_type"] == "eca"
+    rd = GOLD["resnet_deep.py"]                                          # ResNetD: deep stem, "avg" shortcut, no attention
+    assert _tup(km.RESNET200D["num_blocks"]) == _tup(rd["ResNet200D"]["assigns"]["num_blocks"]) and km.RESNET200D["attn"] is None
+    assert rd["ResNetD"]["defaults"]["stem_type"] == "deep" and rd["ResNetD"]["defaults"]["shortcut_type"] == "avg"
+    assert aot["attn_types"] is None and aot["bn_after_attn"] is True and km.RESNET200D["stem_width"] == aot["stem_width"]
     c200 = [c for c in rs["ResNest200"]["calls"] if c["func"] == "ResNest"][0]["kwargs"]
     assert _tup(km.RESNEST200["num_blocks"]) == _tup(c200["num_blocks"]) and km.RESNEST200["stem_width"] == c200["stem_width"]
     assert light["torch_padding"] is True and light["gamma_in_act"] is False and light["use_zero_init_gain"] is False

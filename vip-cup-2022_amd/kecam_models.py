@@ -71,6 +71,9 @@ class _Base:
 # ------------------------------------------------------------------------------------------------
 RESNEST50 = dict(num_blocks=(3, 4, 6, 3), out_channels=(256, 512, 1024, 2048), strides=(1, 2, 2, 2), stem_width=64)
 RESNEST200 = dict(RESNEST50, num_blocks=(3, 24, 36, 3), stem_width=128)        # resnest.py:84-85
+# ResNetD (resnet_family/resnet_deep.py:13-36): the same AotNet skeleton (deep stem, "avg" shortcut) with a plain
+# 3x3 conv + BN + ReLU where ResNeSt has its split attention (aotnet.py:78-81,89-91)
+RESNET200D = dict(RESNEST50, num_blocks=(3, 24, 36, 3), attn=None)
 
 
 def resnest_synth_params(seed: int, classes: int = 1, cfg=RESNEST50) -> Dict[str, torch.Tensor]:
@@ -91,12 +94,16 @@ def resnest_synth_params(seed: int, classes: int = 1, cfg=RESNEST50) -> Dict[str
                 g.bn(f"{n}shortcut_bn", oc)
             g.conv(f"{n}deep_1_conv", 1, 1, cin, hid)
             g.bn(f"{n}deep_1_bn", hid)
-            for r in (1, 2):
-                g.conv(f"{n}deep_2_sa_1_g{r}_conv", 3, 3, hid // 2, hid)
-            g.bn(f"{n}deep_2_sa_1_bn", 2 * hid)
-            g.conv(f"{n}deep_2_sa_2_conv", 1, 1, hid, inter, bias=True)
-            g.bn(f"{n}deep_2_sa_2_bn", inter)
-            g.conv(f"{n}deep_2_sa_3_conv", 1, 1, inter, 2 * hid, bias=True, gain=1.0)
+            if cfg.get("attn", "sa") is None:
+                g.conv(f"{n}deep_2_conv", 3, 3, hid, hid)
+                g.bn(f"{n}deep_2_bn", hid)
+            else:
+                for r in (1, 2):
+                    g.conv(f"{n}deep_2_sa_1_g{r}_conv", 3, 3, hid // 2, hid)
+                g.bn(f"{n}deep_2_sa_1_bn", 2 * hid)
+                g.conv(f"{n}deep_2_sa_2_conv", 1, 1, hid, inter, bias=True)
+                g.bn(f"{n}deep_2_sa_2_bn", inter)
+                g.conv(f"{n}deep_2_sa_3_conv", 1, 1, inter, 2 * hid, bias=True, gain=1.0)
             g.conv(f"{n}deep_3_conv", 1, 1, hid, oc, gain=0.25)
             g.bn(f"{n}3_bn", oc)
             cin = oc
@@ -121,6 +128,12 @@ class ResNest(_Base):
                 if bi == 0 and (s != 1 or cin != oc):
                     blk["sc"] = _cbn(p, f"{n}shortcut_", f"{n}shortcut_", eps, dev)
                 blk["d1"] = _cbn(p, f"{n}deep_1_", f"{n}deep_1_", eps, dev)
+                blk["d3"] = _cbn(p, f"{n}deep_3_", f"{n}3_", eps, dev)
+                if cfg.get("attn", "sa") is None:                       # ResNetD: conv3x3 (stride here) + BN + ReLU
+                    blk["d2"] = _cbn(p, f"{n}deep_2_", f"{n}deep_2_", eps, dev)
+                    self.blocks.append(blk)
+                    cin = oc
+                    continue
                 # the two radix convs = one grouped conv (groups=2) with the "1_" BN folded per output channel
                 kcat = torch.cat([p[f"{n}deep_2_sa_1_g1_conv/kernel"], p[f"{n}deep_2_sa_1_g2_conv/kernel"]], dim=3)
                 w, b = fold_bn(kcat, *[p[f"{n}deep_2_sa_1_bn/{k}"] for k in ("gamma", "beta", "moving_mean", "moving_variance")], eps)
@@ -134,7 +147,6 @@ class ResNest(_Base):
                 w3, b3 = p[f"{n}deep_2_sa_3_conv/kernel"], p[f"{n}deep_2_sa_3_conv/bias"]
                 wd, bd = w3[..., :hid] - w3[..., hid:], b3[:hid] - b3[hid:]
                 blk["sa3"] = ops.make_conv_weight(torch.cat([wd, -wd], dim=3), torch.cat([bd, -bd]), device=dev)
-                blk["d3"] = _cbn(p, f"{n}deep_3_", f"{n}3_", eps, dev)
                 self.blocks.append(blk)
                 cin = oc
         self.stage_ends = list(torch.tensor(cfg["num_blocks"]).cumsum(0).tolist())
@@ -155,6 +167,12 @@ class ResNest(_Base):
             else:
                 sc = y
             d = ops.conv2d(y, blk["d1"], act="relu")
+            if "d2" in blk:                                                     # ResNetD
+                d = ops.conv2d(d, blk["d2"], stride=s, pad=PAD1, act="relu")
+                y = ops.conv2d(d, blk["d3"], residual=sc, act_post="relu")
+                if collect is not None and (i + 1) in self.stage_ends:
+                    collect.append(y)
+                continue
             lg = ops.conv2d(d, blk["sa1"], pad=PAD1, act="relu")                # [B,H,W,2*hid]
             a = ops.se_gate(lg, blk["sa2"], blk["sa3"], "relu", "sigmoid")      # split: the r-softmax weights keep ~22 bits
             d = ops.radix_combine(lg, a, 2)

@@ -47,6 +47,8 @@ MEMBERS: Dict[str, MemberSpec] = {
                                           lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"]), "tfimm_ref", 102.7, "head/fc"),
     "resnest200": MemberSpec("resnest200", "ResNest200-200x200", 200, 1021, lambda seed: km.resnest_synth_params(seed, cfg=km.RESNEST200),
                              lambda p: km.ResNest(p, cfg=km.RESNEST200), "kecam_ref", 29.0),
+    "resnet200d": MemberSpec("resnet200d", "ResNet200D-200x200", 200, 1027, lambda seed: km.resnest_synth_params(seed, cfg=km.RESNET200D),
+                             lambda p: km.ResNest(p, cfg=km.RESNET200D), "kecam_ref", 12.0),
     "eca_nfnet_l2": MemberSpec("eca_nfnet_l2", "ECA_NFNetL2-200x200", 200, 1025, lambda seed: km.nfnet_synth_params(seed, cfg=km.NFNET_L2),
                                lambda p: km.NormFreeNet(p, cfg=km.NFNET_L2), "kecam_ref", 10.6),
     "efficientnet_v2m": MemberSpec("efficientnet_v2m", "EfficientNetV2M-200x200", 200, 1023,
