@@ -19,6 +19,8 @@ CONVNEXT = {  # name -> (embed_dim, nb_blocks, patch_size, first_down)   convnex
     "convnext_small_in22k": ((96, 192, 384, 768), (3, 3, 27, 3), 4, 1),            # :623-632
     "convnext_base_in22k": ((128, 256, 512, 1024), (3, 3, 27, 3), 4, 1),           # :635-644
     "convnext_large_in22ft1k": ((192, 384, 768, 1536), (3, 3, 27, 3), 4, 1),       # :518-527
+    "convnext_base_384_in22ft1k": ((128, 256, 512, 1024), (3, 3, 27, 3), 4, 1),    # :575-584
+    "convnext_large_384_in22ft1k": ((192, 384, 768, 1536), (3, 3, 27, 3), 4, 1),   # :587-596
 }
 
 

@@ -32,6 +32,7 @@ def test_manifest_and_batch_table():
     assert ensemble.REF_BATCH == 8 * 16 and ensemble.NAME2BS == GOLD["main.py"]["NAME2BS"]
     assert ensemble.ref_batch("ResNetRS200-200x200") == 256 and ensemble.ref_batch("ResNetRS50-200x200") == 128
     # the earlier ensembles' members that are re-configurations of graphs built here carry the manifest's naming scheme
+    assert set(GOLD["main.py"]["NAME2BS"]) - {zoo.MEMBERS[k].ckpt_name for k in zoo.MEMBERS} == {"HorNetBase-200x200"}
     for key in ("resnet_rs200", "convnext_base_in22k", "convnext_large_in22ft1k", "gcvit_base", "resnest200", "eca_nfnet_l2", "resnet200d",
                 "efficientnet_v2m", "efficientnet_v2l"):
         assert zoo.MEMBERS[key].ckpt_name in GOLD["main.py"]["NAME2BS"], key
@@ -153,6 +154,7 @@ def test_tfimm_configs():
         kw = [c for c in GOLD["convnext.py"][name]["calls"] if c["func"] == "ConvNeXtConfig"][0]["kwargs"]
         cfg = tm.CONVNEXT_CONFIGS[name]
         assert kw["name"] == name and "first_down" not in kw and "patch_size" not in kw      # stride-2 4x4 stem (first_down = 1)
+        assert kw.get("input_size", (224, 224)) in ((224, 224), [224, 224], (384, 384), [384, 384])
         assert _tup(cfg.embed_dim) == _tup(kw["embed_dim"]) and _tup(cfg.nb_blocks) == _tup(kw["nb_blocks"])
         assert (cfg.patch_size, cfg.first_down) == (4, 1)
         assert _tup(tfimm_ref.CONVNEXT[name]) == (_tup(kw["embed_dim"]), _tup(kw["nb_blocks"]), 4, 1)

@@ -88,7 +88,8 @@ out = {
     "aotnet.py": {n: function_literals(K + "aotnet/aotnet.py", n) for n in ("AotNet",)},
     "vit.py": {n: function_literals(T + "vit.py", n) for n in ("vit_tiny_patch16_224", "vit_small_patch16_224", "vit_base_patch16_224")},
     "convnext.py": {n: function_literals(T + "convnext.py", n)
-                    for n in ("convnext_tiny_in22k", "convnext_small_in22k", "convnext_base_in22k", "convnext_large_in22ft1k")},
+                    for n in ("convnext_tiny_in22k", "convnext_small_in22k", "convnext_base_in22k", "convnext_large_in22ft1k",
+                              "convnext_base_384_in22ft1k", "convnext_large_384_in22ft1k")},
 }
 json.dump(out, open(OUT, "w"), indent=1, sort_keys=True)
 print("wrote", OUT, os.path.getsize(OUT), "bytes")

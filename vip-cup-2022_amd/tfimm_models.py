@@ -149,6 +149,9 @@ CONVNEXT_CONFIGS = {
     "convnext_small_in22k": ConvNeXtConfig("convnext_small_in22k", nb_blocks=(3, 3, 27, 3)),                          # :623-632
     "convnext_base_in22k": ConvNeXtConfig("convnext_base_in22k", embed_dim=(128, 256, 512, 1024), nb_blocks=(3, 3, 27, 3)),    # :635-644
     "convnext_large_in22ft1k": ConvNeXtConfig("convnext_large_in22ft1k", embed_dim=(192, 384, 768, 1536), nb_blocks=(3, 3, 27, 3)),  # :518-527
+    # the 384-pixel fine-tunes: the same graphs (the ensemble runs them at 200 x 200 anyway)            :575-596
+    "convnext_base_384_in22ft1k": ConvNeXtConfig("convnext_base_384_in22ft1k", embed_dim=(128, 256, 512, 1024), nb_blocks=(3, 3, 27, 3)),
+    "convnext_large_384_in22ft1k": ConvNeXtConfig("convnext_large_384_in22ft1k", embed_dim=(192, 384, 768, 1536), nb_blocks=(3, 3, 27, 3)),
 }
 
 

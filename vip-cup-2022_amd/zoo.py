@@ -57,6 +57,12 @@ MEMBERS: Dict[str, MemberSpec] = {
     "efficientnet_v2l": MemberSpec("efficientnet_v2l", "EfficientNetV2L-200x200", 200, 1024,
                                    lambda seed: km.effnet_synth_params("EfficientNetV2L", seed),
                                    lambda p: km.EfficientNet(p, "EfficientNetV2L"), "kecam_ref", 9.8),
+    "convnext_base_384_in22ft1k": MemberSpec("convnext_base_384_in22ft1k", "convnext_base_384_in22ft1k-200x200", 200, 1031,
+        lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_base_384_in22ft1k"], seed),
+        lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_base_384_in22ft1k"]), "tfimm_ref", 45.8, "head/fc"),
+    "convnext_large_384_in22ft1k": MemberSpec("convnext_large_384_in22ft1k", "convnext_large_384_in22ft1k-200x200", 200, 1033,
+        lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_large_384_in22ft1k"], seed),
+        lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_large_384_in22ft1k"]), "tfimm_ref", 102.7, "head/fc"),
     "gcvit_base": MemberSpec("gcvit_base", "GCViTBase-224x224", 224, 1022,
                              lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_base"], seed),
                              lambda p: gcvit.GCViT(p, **gcvit.NAME2CONFIG["gcvit_base"]), "gcvit_ref", 14.3, "head"),
