@@ -187,6 +187,12 @@ int vip_scale_add_act2_f16(const void* x, const void* scale, const void* residua
 int vip_scale_add_act3_f16(const void* x, const void* scale, int scale_planes, const void* residual, void* y, void* y2,
                            int B, int HW, int C, int act, int act2, void* stream);
 
+/* Elementwise product of channel slices of two row-major tensors:  y[m, y_off + c] = a[m, a_off + c] * b[m, b_off + c],
+ * c < C (fp32 product, one rounding).  Replaces the `pw * dw` gating products of kecam hornet.py:104-107 (gnconv), whose
+ * operands are slices of wider tensors (tf.split).  Everything a multiple of 8 halfs. */
+int vip_mul_f16(const void* a, const void* b, void* y, long rows, int C, int lda, int a_off, int ldb, int b_off,
+                int ldy, int y_off, void* stream);
+
 /* ResNeSt split-attention combine (kecam resnest/resnest.py:57-61): out[b,p,c] = sum_r x[b,p,r*C+c] *
  * scale[b,r*C+c].  x f16 [B,HW,radix*C]; scale f16 [B,radix*C] (the r-softmax weights); out [B,HW,C]. */
 int vip_radix_combine_f16(const void* x, const void* scale, void* y, int B, int HW, int C, int radix,

@@ -140,6 +140,10 @@ def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
     return _r(R.act(y, _an(act)), "saa")
 
 
+def mul(a, b, c, a_off=0, b_off=0):
+    return _r(a[..., a_off:a_off + c] * b[..., b_off:b_off + c], "saa")
+
+
 def radix_combine(x, scale, radix=2):
     B, H, W, RC = x.shape
     return _r((x * _gate(scale)[:, None, None, :]).reshape(B, H, W, radix, RC // radix).sum(3), "saa")
@@ -188,7 +192,7 @@ def patched(round_act=False):
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops
     names = ["conv2d", "dense", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
-             "scale_add_act", "radix_combine", "window_attention", "mhsa", "vit_tokens", "to_device_nhwc8"]
+             "scale_add_act", "mul", "radix_combine", "window_attention", "mhsa", "vit_tokens", "to_device_nhwc8"]
     saved = {n: getattr(ops, n) for n in names}
     old = ROUND_ACT
     ROUND_ACT = round_act

@@ -58,6 +58,10 @@ def test_argument_checks_do_not_need_a_gpu():
     # split-output Dense: a batch of pooled vectors, at most 256 rows
     st = lib.vip_gemm_split_f16(p, p, None, p, 257, 64, 64, 64, 64, 4, None)
     assert st == -3 and b"256" in lib.vip_last_error()
+    st = lib.vip_mul_f16(p, p, p, 4, 16, 32, 24, 32, 0, 16, 0, None)          # slice 24..40 of a 32-wide row
+    assert st == -1 and b"exceeds" in lib.vip_last_error()
+    st = lib.vip_mul_f16(p, p, p, 4, 12, 32, 0, 32, 0, 16, 0, None)
+    assert st == -2
     st = lib.vip_scale_add_act3_f16(p, p, 3, None, p, None, 1, 4, 8, 0, 0, None)
     assert st == -1 and b"scale_planes" in lib.vip_last_error()
     # gated conv: only pointwise convolutions take a gate

@@ -121,3 +121,22 @@ def test_kecam_legacy_configs_reduced_depth(report):
         _compare(report, "EfficientNetV2M d1222221", ca, cb, m.logits(xd).cpu(), z_ref)
     finally:
         del km.EFFNET[name], ref.EFFNET[name]
+
+
+def test_hornet_reduced_depth(report):
+    """HorNetBase (hornet.py:196-198) at depths (1,1,2,1): recursive gated convolution with 2..5 orders, depthwise 7x7 on
+    the 2C - C/2^(n-1) gate channels, channel-slice products, folded layer scales, LN -> Dense head."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import hornet, ops
+    from oracle import hornet_ref
+    cfg = dict(hornet.CONFIGS["hornet_base"], num_blocks=(1, 1, 2, 1))
+    p = hornet.synth_params(cfg, 1028)
+    x = _images(2, 200).to(torch.float16).to(torch.float32)
+    ca, cb = [], []
+    with torch.no_grad():
+        hornet_ref.forward_features(p, x, cfg, collect=ca)
+        z_ref = hornet_ref.forward_logits(p, x, cfg)
+    m = hornet.HorNet(p, **cfg)
+    xd = ops.to_device_nhwc8(x)
+    m.features(xd, collect=cb)
+    _compare(report, "HorNetBase d1121", ca, cb, m.logits(xd).cpu(), z_ref)

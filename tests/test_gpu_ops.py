@@ -426,3 +426,14 @@ def test_window_attention_softmax_spike(report):
     got = ops.window_attention(dev(qkv), None, table.cuda(), heads, ws, 32 ** -0.5)
     torch.cuda.synchronize()
     check(report, "window_attn spike", got, ref, tol=3e-3)
+
+
+def test_mul_channel_slices(report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(77)
+    a = h(torch.randn(3, 5, 7, 64, generator=g))
+    b = h(torch.randn(3, 5, 7, 224, generator=g))
+    got = ops.mul(dev(a), dev(b), 32, a_off=16, b_off=96)
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu().float(), h(a[..., 16:48] * b[..., 96:128]))
+    report("[ops] mul: channel-slice product exact (fp32 product, one rounding)")

@@ -32,7 +32,7 @@ def test_manifest_and_batch_table():
     assert ensemble.REF_BATCH == 8 * 16 and ensemble.NAME2BS == GOLD["main.py"]["NAME2BS"]
     assert ensemble.ref_batch("ResNetRS200-200x200") == 256 and ensemble.ref_batch("ResNetRS50-200x200") == 128
     # the earlier ensembles' members that are re-configurations of graphs built here carry the manifest's naming scheme
-    assert set(GOLD["main.py"]["NAME2BS"]) - {zoo.MEMBERS[k].ckpt_name for k in zoo.MEMBERS} == {"HorNetBase-200x200"}
+    assert not set(GOLD["main.py"]["NAME2BS"]) - {zoo.MEMBERS[k].ckpt_name for k in zoo.MEMBERS}     # all twelve are registered
     for key in ("resnet_rs200", "convnext_base_in22k", "convnext_large_in22ft1k", "gcvit_base", "resnest200", "eca_nfnet_l2", "resnet200d",
                 "efficientnet_v2m", "efficientnet_v2l"):
         assert zoo.MEMBERS[key].ckpt_name in GOLD["main.py"]["NAME2BS"], key
@@ -158,3 +158,21 @@ def test_tfimm_configs():
         assert _tup(cfg.embed_dim) == _tup(kw["embed_dim"]) and _tup(cfg.nb_blocks) == _tup(kw["nb_blocks"])
         assert (cfg.patch_size, cfg.first_down) == (4, 1)
         assert _tup(tfimm_ref.CONVNEXT[name]) == (_tup(kw["embed_dim"]), _tup(kw["nb_blocks"]), 4, 1)
+
+
+def test_hornet_configs():
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import hornet
+    from oracle import hornet_ref
+    hn = GOLD["hornet.py"]
+    base = hn["HorNet"]["defaults"]
+    for name, fn in (("hornet_tiny", "HorNetTiny"), ("hornet_small", "HorNetSmall"), ("hornet_base", "HorNetBase"),
+                     ("hornet_large", "HorNetLarge")):
+        want = dict(num_blocks=base["num_blocks"], embed_dim=hn[fn]["assigns"].get("embed_dim", base["embed_dim"]),
+                    mlp_ratio=base["mlp_ratio"], gn_split=base["gn_split"], scale=base["scale"])
+        assert "use_global_local_filter" not in hn[fn]["assigns"]          # the plain (depthwise 7x7) variants
+        for table in (hornet.CONFIGS, hornet_ref.CONFIGS):
+            for k, v in want.items():
+                assert _tup(table[name][k]) == _tup(v), (name, k)
+    assert hn["gnconv"]["defaults"]["dw_kernel_size"] == 7 and base["activation"] == "gelu" and base["layer_scale"] >= 0
+    assert hornet.split_dims(128, 3) == [32, 64, 128]

@@ -84,6 +84,8 @@ out = {
     "resnest.py": {n: function_literals(K + "resnest/resnest.py", n) for n in ("ResNest", "ResNest50", "ResNest200")},
     "nfnets.py": {n: function_literals(K + "nfnets/nfnets.py", n)
                   for n in ("NormFreeNet", "NormFreeNet_Light", "ECA_NFNetL0", "ECA_NFNetL2")},
+    "hornet.py": {n: function_literals(K + "hornet/hornet.py", n)
+                  for n in ("HorNet", "HorNetTiny", "HorNetSmall", "HorNetBase", "HorNetLarge", "gnconv", "block")},
     "resnet_deep.py": {n: function_literals(K + "resnet_family/resnet_deep.py", n) for n in ("ResNetD", "ResNet200D")},
     "aotnet.py": {n: function_literals(K + "aotnet/aotnet.py", n) for n in ("AotNet",)},
     "vit.py": {n: function_literals(T + "vit.py", n) for n in ("vit_tiny_patch16_224", "vit_small_patch16_224", "vit_base_patch16_224")},

@@ -54,6 +54,7 @@ SIGNATURES = {
     "vip_scale_add_act_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_scale_add_act2_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vip_scale_add_act3_f16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vip_mul_f16": (_i, [_vp, _vp, _vp, C.c_long] + [_i] * 7 + [_vp]),
     "vip_radix_combine_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_radix_combine2_f16": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "vip_window_attn_fwd_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _vp]),

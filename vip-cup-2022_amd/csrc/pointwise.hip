@@ -420,6 +420,21 @@ extern "C" int vip_gap_dense_f32(const void* x, const float* W, const float* bia
 // ResNeSt split-attention combine (kecam resnest/resnest.py:57-61): out[b,p,c] = sum_r x[b,p,r*C+c] * s[b,r*C+c]
 // ---------------------------------------------------------------------------------------------
 namespace {
+// y[m, y_off + c] = a[m, a_off + c] * b[m, b_off + c]: channel slices of wider row-major tensors, 8 channels per thread
+__global__ __launch_bounds__(256) void mul_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ y,
+                                                  long total8, int C8, int lda, int ldb, int ldy) {
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total8; idx += (long)gridDim.x * 256) {
+        const int c8 = (int)(idx % C8);
+        const long m = idx / C8;
+        U4H8 u, v, o;
+        u.u = *reinterpret_cast<const uint4*>(a + m * lda + c8 * 8);
+        v.u = *reinterpret_cast<const uint4*>(b + m * ldb + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.e[j] = (f16)((float)u.e[j] * (float)v.e[j]);
+        *reinterpret_cast<uint4*>(y + m * ldy + c8 * 8) = o.u;
+    }
+}
+
 __global__ __launch_bounds__(256) void radix_combine_kernel(const f16* __restrict__ x, const f16* __restrict__ s,
                                                             f16* __restrict__ y, long total8, int HW, int C8, int radix,
                                                             int planes) {
@@ -468,4 +483,17 @@ extern "C" int vip_radix_combine2_f16(const void* x, const void* scale, int scal
 extern "C" int vip_radix_combine_f16(const void* x, const void* scale, void* y, int B, int HW, int C, int radix,
                                      void* stream) {
     return vip_radix_combine2_f16(x, scale, 1, y, B, HW, C, radix, stream);
+}
+
+extern "C" int vip_mul_f16(const void* a, const void* b, void* y, long rows, int C, int lda, int a_off, int ldb, int b_off,
+                           int ldy, int y_off, void* stream) {
+    VIP_REQUIRE(a && b && y, VIP_ERR_BAD_ARG, "vip_mul_f16: null pointer");
+    VIP_REQUIRE(rows > 0 && C > 0 && a_off >= 0 && b_off >= 0 && y_off >= 0, VIP_ERR_BAD_ARG, "vip_mul_f16: bad size");
+    VIP_REQUIRE(C % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldy % 8 == 0 && a_off % 8 == 0 && b_off % 8 == 0 && y_off % 8 == 0,
+                VIP_ERR_ALIGNMENT, "vip_mul_f16: C, leading dimensions and offsets must be multiples of 8 halfs");
+    VIP_REQUIRE(a_off + C <= lda && b_off + C <= ldb && y_off + C <= ldy, VIP_ERR_BAD_ARG, "vip_mul_f16: slice exceeds its row");
+    const long total8 = rows * (C / 8);
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(total8)), dim3(256), 0, (hipStream_t)stream, (const f16*)a + a_off,
+                       (const f16*)b + b_off, (f16*)y + y_off, total8, C / 8, lda, ldb, ldy);
+    return vip_launch_status("vip_mul_f16");
 }

@@ -492,6 +492,19 @@ def cls_dense_f32(tokens, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     return out
 
 
+def mul(a: torch.Tensor, b: torch.Tensor, c: int, a_off: int = 0, b_off: int = 0) -> torch.Tensor:
+    """``a[..., a_off:a_off+c] * b[..., b_off:b_off+c]`` -> contiguous ``[..., c]`` (the operands are read in place as
+    channel slices of their full tensors)."""
+    _chk16(a, "mul.a")
+    _chk16(b, "mul.b")
+    assert a.shape[:-1] == b.shape[:-1]
+    rows = a.numel() // a.shape[-1]
+    out = torch.empty((*a.shape[:-1], c), dtype=torch.float16, device=a.device)
+    st = _abi.lib().vip_mul_f16(_p(a), _p(b), _p(out), rows, c, a.shape[-1], a_off, b.shape[-1], b_off, c, 0, _stream())
+    _abi.check(st, "vip_mul_f16")
+    return out
+
+
 def radix_combine(x, scale, radix: int = 2):
     """ResNeSt split-attention combine: x ``[B,H,W,radix*C]``, scale ``[B,radix*C]`` or split ``[B,2,radix*C]``
     -> ``[B,H,W,C]``."""

@@ -11,7 +11,7 @@ from typing import Callable, Dict, List, Tuple
 import numpy as np
 import torch
 
-from . import gcvit, kecam_models as km, resnet_rs, tfimm_models as tm
+from . import gcvit, hornet, kecam_models as km, resnet_rs, tfimm_models as tm
 
 
 @dataclass
@@ -63,6 +63,9 @@ MEMBERS: Dict[str, MemberSpec] = {
     "convnext_large_384_in22ft1k": MemberSpec("convnext_large_384_in22ft1k", "convnext_large_384_in22ft1k-200x200", 200, 1033,
         lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_large_384_in22ft1k"], seed),
         lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_large_384_in22ft1k"]), "tfimm_ref", 102.7, "head/fc"),
+    "hornet_base": MemberSpec("hornet_base", "HorNetBase-200x200", 200, 1028,
+                              lambda seed: hornet.synth_params(hornet.CONFIGS["hornet_base"], seed),
+                              lambda p: hornet.HorNet(p, **hornet.CONFIGS["hornet_base"]), "hornet_ref", 11.6),
     "gcvit_base": MemberSpec("gcvit_base", "GCViTBase-224x224", 224, 1022,
                              lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_base"], seed),
                              lambda p: gcvit.GCViT(p, **gcvit.NAME2CONFIG["gcvit_base"]), "gcvit_ref", 14.3, "head"),
