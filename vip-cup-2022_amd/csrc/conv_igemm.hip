@@ -1153,15 +1153,17 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
             return launch_pwk<2, 1>(a, mode, s);
         }
     }
-    {   // Stems (Cin <= 16: K = 72 / 128, a handful of taps per 64-k chunk) run on the pointwise kernel with im2col staging:
-        // 277 vs 385 us on the EfficientNet stems.  For wider convolutions the two kernels trade places shape by shape
-        // (total 35.9 vs 36.1 ms over the ensemble's launches), so those stay on the tile kernel.
+    {   // k x k convolutions on the pointwise kernel with im2col staging (64 px x 128 ch wave tiles, half the LDS fragment
+        // reads per MFMA of the 64 x 64 tiles below): stems (Cin <= 16: 277 vs 385 us on the EfficientNet stems) and every
+        // layer with at least 32 K pixels - measured per shape on the ensemble after the MFMA-priority change: +3..+25 %
+        // (ResNeSt's grouped 3x3: 585 -> 726, 721 -> 853 TF), except the 7 x 7-pixel stages (M = 12 544: 637 -> 497 TF),
+        // which keep the tile kernel.  VIP_PWK_CONV: 1 = every eligible conv (tests), -1 = stems only.
         int mode = -1;
         if (!residual && d->act_post == VIP_ACT_NONE) mode = d->act_pre;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_NONE) mode = 5;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_RELU) mode = 6;
-        static const int im2col_all = getenv("VIP_PWK_CONV") ? atoi(getenv("VIP_PWK_CONV")) : 0;   // 1: every eligible conv (tests)
-        if ((cin_g <= 16 || im2col_all) && mode >= 0 && !gate && a.x_span_bytes < 0xFFFFFFF0L && d->H < 30000 &&
+        static const int im2col_all = getenv("VIP_PWK_CONV") ? atoi(getenv("VIP_PWK_CONV")) : 0;
+        if ((cin_g <= 16 || im2col_all > 0 || (im2col_all == 0 && M >= 32768)) && mode >= 0 && !gate && a.x_span_bytes < 0xFFFFFFF0L && d->H < 30000 &&
             d->W < 30000 && d->pt < 16 && d->pl < 16)
             return cout_g <= 64 ? launch_pwk_conv<1>(a, mode, d->groups, s) : launch_pwk_conv<2>(a, mode, d->groups, s);
     }

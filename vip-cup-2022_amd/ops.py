@@ -176,8 +176,8 @@ def gemm_kernel_name(M: int, K: int, kh: int, kw: int, sh: int, sw: int, pad, gr
         return "rows_gemm_kernel"
     if pointwise and epi_ok:
         return "pw_gemm_kernel" if (K <= 256 and M >= 65536) else "pwk_gemm_kernel"
-    if epi_ok and cin_g <= 16:
-        return "pwk_gemm_kernel"          # stems: im2col staging on the pointwise kernel
+    if epi_ok and (cin_g <= 16 or M >= 32768):
+        return "pwk_gemm_kernel"          # stems and every layer with >= 32 K pixels: im2col staging on the pointwise kernel
     return "conv_igemm_kernel"
 
 
