@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 from oracle import ops_ref as R  # noqa: E402
 from tools.make_synth import synth_jpeg  # noqa: E402
 
-N_IMG = 16
+N_IMG = int(os.environ.get("VIP_E2E_N", "16"))   # 16 in the suite; larger samples on demand
 # BASELINE.json north_star asks for |z_hip - z_ref| <= 1e-3 on the sigmoid logit of the CSV score.  The score main.py
 # thresholds is the ensemble-mean probability: asserted to 1e-3 here (measured 2.7e-4).  The individual members run on
 # synthetic checkpoints whose calibrated heads turn a 1e-3 relative feature error into several 1e-3 on a logit whose

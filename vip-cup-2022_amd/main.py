@@ -53,11 +53,16 @@ def main(argv=None):
     dist = None
     if not torch.cuda.is_available():
         raise SystemExit("vipcup_amd main: no GPU visible — the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    backend = os.environ.get("VIP_DIST_BACKEND", "nccl")     # gloo: several ranks may share one card (rehearsals on a 1-GPU box)
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     infer_path = os.path.dirname(os.path.abspath(a.input_csv))   # main.py:161-164
     test_csv = pd.read_csv(a.input_csv)
