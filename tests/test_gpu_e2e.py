@@ -33,7 +33,7 @@ def _logit(p):
 def test_main_cli_matches_oracle(tmp_path, report):
     import vipcup_amd  # noqa: F401
     from vipcup_amd import main as cli, zoo
-    idx = list(range(100, 100 + N_IMG - 1)) + [149]          # includes one 256x192 image (resize branch)
+    idx = list(range(100, 100 + N_IMG - 1)) + [149 if N_IMG <= 50 else 49]   # includes a 256x192 image (resize branch), no duplicates
     names = []
     for i in idx:
         n = f"img_{i:05d}.jpg"
