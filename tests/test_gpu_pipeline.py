@@ -85,3 +85,31 @@ def test_tta_ops(report):
     for i in range(4):
         assert (got[i] - ref[i]).abs().max().item() <= 1e-3, i
     report("[pipeline] tta flips/gray ok")
+
+
+def test_tiny_gray_and_odd_images_through_decode_and_resize(report):
+    """1x1, 3x5, 17x13 colour and grayscale files in one batch with a 200x200 one: decode bit-exact, resize vs the oracle."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import pipeline
+    from tools.make_synth import synth_pixels
+    px = synth_pixels(11)
+    raws = []
+    for hw, mode, kw in (((1, 1), "RGB", dict(quality=90)), ((3, 5), "RGB", dict(quality=75, subsampling=2)),
+                         ((17, 13), "L", dict(quality=80)), ((9, 31), "RGB", dict(quality=60, subsampling=1, progressive=True)),
+                         ((200, 200), "RGB", dict(quality=85))):
+        b = io.BytesIO()
+        Image.fromarray(px[:hw[0], :hw[1]]).convert(mode).save(b, format="JPEG", **kw)
+        raws.append(b.getvalue())
+    batch = pipeline.decode_jpegs(raws)
+    torch.cuda.synchronize()
+    rgb = batch.rgb.cpu().numpy()
+    for i, raw in enumerate(raws):
+        h, w = batch.sizes_host[i]
+        assert np.array_equal(rgb[i, :h, :w], _pil(raw)), i
+    got = batch.resized(200, 200).float().cpu()
+    worst = 0.0
+    for i, raw in enumerate(raws):
+        ref16 = R.decode_resize_normalize(_pil(raw), 200, 200).to(torch.float16).float()
+        worst = max(worst, (got[i, ..., :3] - ref16).abs().max().item())
+    report(f"[pipeline] tiny/gray/odd images: decode bit-exact, resize max |hip - oracle| = {worst:.3e}")
+    assert worst <= 1e-3
