@@ -93,6 +93,16 @@ int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, const v
 int vip_conv2d_gated_nhwc_f16(const void* x, const void* gate, const void* w, const float* bias, const void* residual,
                               void* y, const vip_conv_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * vip_conv2d_nhwc_f16 with two-term weights:  y = epilogue( (w_hi + w_lo) * x ),  w_lo = fp16(W32 - fp16(W32)) in the layout
+ * of w_hi - the layer computes with ~22-bit weights.  For the short-K, many-pixel 1x1 convolutions (EfficientNet expand
+ * convolutions, kecam efficientnet_v2.py:63-66): they are HBM-bound, so the second MFMA per fragment is free, and their
+ * fp16 weight rounding is what dominates EfficientNetV1-B4's logit error (Numerics).
+ * Only 1x1 stride-1 ungrouped convolutions with K <= 256 and an (activation) or (residual [+ReLU]) epilogue.
+ * ------------------------------------------------------------------------------------------ */
+int vip_conv2d_hilo_nhwc_f16(const void* x, const void* w_hi, const void* w_lo, const float* bias, const void* residual,
+                             void* y, const vip_conv_desc* d, void* stream);
+
 /* Dense / 1x1 convenience wrapper: C[M,N] = act_post(act_pre(A[M,K] @ W[N,K]^T + bias) + residual).
  * Replaces tf.keras.layers.Dense (gcvit/layers/attention.py:25,33, feature.py:20-22;
  * tfimm/layers/transformers.py:192-205; all classifier heads). */

@@ -27,7 +27,8 @@ def _an(a):
 
 def _w(cw):
     k = cw.kh * cw.kw * cw.cin_g
-    return cw.w.float()[:, :k].reshape(cw.cout, cw.kh, cw.kw, cw.cin_g).permute(1, 2, 3, 0)
+    w = cw.w.float() if getattr(cw, "w_lo", None) is None else cw.w.float() + cw.w_lo.float()     # two-term weights
+    return w[:, :k].reshape(cw.cout, cw.kh, cw.kw, cw.cin_g).permute(1, 2, 3, 0)
 
 
 def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=None, out=None, cin_off=0, cout_off=0,

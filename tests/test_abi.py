@@ -64,6 +64,11 @@ def test_argument_checks_do_not_need_a_gpu():
     assert st == -2
     st = lib.vip_scale_add_act3_f16(p, p, 3, None, p, None, 1, 4, 8, 0, 0, None)
     assert st == -1 and b"scale_planes" in lib.vip_last_error()
+    # two-term weights: pointwise, K <= 256 only
+    d = _abi.ConvDesc(B=1, H=8, W=8, Cin=512, Cout=16, kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Ho=8, Wo=8, groups=1, ldx=512,
+                      cin_off=0, ldy=16, cout_off=0, ldr=0, res_off=0, ldw=512, act_pre=0, act_post=0)
+    st = lib.vip_conv2d_hilo_nhwc_f16(p, p, p, None, None, p, C.byref(d), None)
+    assert st == -3 and b"K <= 256" in lib.vip_last_error()
     # gated conv: only pointwise convolutions take a gate
     d = _abi.ConvDesc(B=1, H=8, W=8, Cin=16, Cout=16, kh=3, kw=3, sh=1, sw=1, pt=1, pl=1, Ho=8, Wo=8, groups=1, ldx=16,
                       cin_off=0, ldy=16, cout_off=0, ldr=0, res_off=0, ldw=144, act_pre=0, act_post=0)

@@ -157,12 +157,12 @@ def test_conv2d_gated(B, H, W, Cin, Cout, use_res, report):
 
 
 def test_conv2d_im2col_pointwise_kernel_all_cases():
-    """The im2col staging of the pointwise kernel is only dispatched for stems by default; VIP_PWK_CONV=1 routes every
+    """The im2col staging of the pointwise kernel is dispatched for stems and for layers with >= 32 K pixels by default; VIP_PWK_CONV=1 routes every
     eligible convolution through it (the switch is read once per process, hence the subprocess)."""
     import os, subprocess, sys
     env = dict(os.environ, VIP_PWK_CONV="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k",
-                        "test_conv2d and not im2col", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                        "test_conv2d and not im2col and not two_term", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
@@ -437,3 +437,34 @@ def test_mul_channel_slices(report):
     torch.cuda.synchronize()
     assert torch.equal(got.cpu().float(), h(a[..., 16:48] * b[..., 96:128]))
     report("[ops] mul: channel-slice product exact (fp32 product, one rounding)")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,use_res", [(4, 56, 56, 32, 192, "silu", False), (2, 28, 28, 112, 672, "silu", False),
+                                                        (3, 28, 28, 160, 40, None, True), (2, 24, 24, 256, 72, "relu", False)])
+def test_conv2d_two_term_weights(B, H, W, Cin, Cout, act, use_res, report):
+    """vip_conv2d_hilo_nhwc_f16: with w + w_lo the error that is COHERENT over pixels (the per-channel mean of y - y_ref,
+    what fp16 weight rounding leaves behind) drops by orders of magnitude; per-element error stays at fp16 output rounding."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    # channel means that vary along K: the weight-rounding errors add up coherently over pixels and error-diffusion
+    # rounding (which assumes a flat mean) cannot cancel them
+    x = h(torch.rand(B, H, W, Cin, generator=g) * 0.5 + torch.rand(Cin, generator=g) * 2.0)
+    w = torch.randn(1, 1, Cin, Cout, generator=g) / math.sqrt(Cin)  # fp32 weights (NOT fp16-representable)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    res = h(torch.randn(B, H, W, Cout, generator=g)) if use_res else None
+    ref = R.act(R.conv2d(x, w, bias, 1, (0, 0, 0, 0), 1), act)
+    if use_res:
+        ref = ref + res
+    rd = None if res is None else dev(res)
+    one = ops.conv2d(dev(x), ops.make_conv_weight(w, bias), act=act, residual=rd).float().cpu()
+    cw = ops.make_conv_weight(w, bias, hilo=True)
+    assert cw.w_lo is not None and cw.err is None
+    two = ops.conv2d(dev(x), cw, act=act, residual=rd).float().cpu()
+    torch.cuda.synchronize()
+    check(report, f"conv2d two-term weights {B}x{H}x{W}x{Cin}->{Cout}", two, ref)
+    coh1 = (one - ref).mean(dim=(0, 1, 2)).abs().max().item()
+    coh2 = (two - ref).mean(dim=(0, 1, 2)).abs().max().item()
+    report(f"[ops] per-channel mean error: fp16 weights {coh1:.3e} -> two-term {coh2:.3e}")
+    assert coh2 < 0.25 * coh1, (coh1, coh2)
+    with pytest.raises(Exception):
+        ops.conv2d(dev(x), cw, gate=split_gate(torch.rand(B, Cin)))   # gated layers cannot carry them

@@ -41,6 +41,7 @@ SIGNATURES = {
     "vip_last_error": (C.c_char_p, []),
     "vip_conv2d_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
     "vip_conv2d_gated_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
+    "vip_conv2d_hilo_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
     "vip_gemm_bias_act_f16": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp]),
     "vip_mlp_fused_supported": (_i, [_i, _i, _i, _i]),
     "vip_mlp_fused_f16": (_i, [_vp, _vp, _vp, _f] + [_vp] * 6 + [_i] * 9 + [_vp]),

@@ -49,6 +49,7 @@ struct ConvArgs {
     int bias_elems;
     int act_pre, act_post;
     int m_blocks, n_blocks;
+    const f16* w_lo;   // optional low half of the weights, fp16(W32 - fp16(W32)), same layout as w; streaming kernel only
     const f16* gate;   // optional per-image input-channel gate [B][2][K] (hi, lo planes of a squeeze-excite scale, folded into the load); pwk only
     int y_lo_off;      // rows kernel: != 0 -> also write fp16(v - fp16(v)) this many halfs after each output (split gate)
     int gate_hw;       // pixels per image (image index of pixel m = m / gate_hw)
@@ -337,7 +338,9 @@ __device__ __forceinline__ void pw_epilogue(const ConvArgs& a, f32x4 (&acc)[PT][
 }
 
 // mode = act_pre (0..4) without residual, 5 = residual, 6 = residual + post-ReLU (both with act_pre none)
-template <int KS, int PT, bool PRE>
+// HILO: the LDS row of a channel holds its fp16 weights followed by their low halves (w_lo); every activation fragment is
+// multiplied by both, so the layer computes with ~22-bit weights.  These layers are HBM-bound, the second MFMA is free.
+template <int KS, int PT, bool PRE, bool HILO>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(ConvArgs a, int nb_ch, int lds_stride, int n_tiles, int mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,15 +353,20 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(ConvArgs a, int nb_ch, 
     {   // stage the weight slice: LDS row j <-> channel n_chunk0 + (j & ~63) + perm(j & 63) (fragment order)
         const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
             (void*)a.w, 0, (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)a.w_lo, 0, HILO ? (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw) : 0u, 0x00020000);
         const int cpr = KS * 4;                      // 16-byte chunks per (zero-padded) row
-        for (int i = tid; i < nch * cpr; i += 256) {
-            const int j = i / cpr, c = i - j * cpr;
+        constexpr int HALVES = HILO ? 2 : 1;
+        for (int i = tid; i < nch * cpr * HALVES; i += 256) {
+            const int j = i / (cpr * HALVES), c2 = i - j * (cpr * HALVES);
+            const int c = c2 < cpr ? c2 : c2 - cpr;
             const int t = (j >> 4) & 3, r = j & 15;
             const int ch = n_chunk0 + (j & ~63) + (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3);
             const bool ok = (ch < a.Cout_g) & (c * 8 < a.K);
-            const uint4 v = __builtin_bit_cast(
-                uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? (unsigned)((ch * a.ldw + c * 8) * 2) : OOB, 0, 0));
-            *reinterpret_cast<uint4*>(smem + j * lds_stride + c * 16) = v;
+            const unsigned off = ok ? (unsigned)((ch * a.ldw + c * 8) * 2) : OOB;
+            const uint4 v = __builtin_bit_cast(uint4, c2 < cpr ? __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0)
+                                                               : __builtin_amdgcn_raw_buffer_load_b128(rwl, off, 0, 0));
+            *reinterpret_cast<uint4*>(smem + j * lds_stride + c2 * 16) = v;
         }
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
             (void*)a.bias, 0, a.bias ? (unsigned)(a.bias_elems * 4) : 0u, 0x00020000);
@@ -416,6 +424,15 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(ConvArgs a, int nb_ch, 
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[ks][p].h, ks == 0 ? bv[nt] : acc[p][nt], 0, 0, 0);
+                if constexpr (HILO) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + nt * 16 * lds_stride + (KS + ks) * 64);
+#pragma unroll
+                    for (int p = 0; p < PT; ++p)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[ks][p].h, acc[p][nt], 0, 0, 0);
+                }
             }
             const int m_base = m0 + l15, n_first = n_chunk0 + sub + lq * 8;
             switch (mode) {
@@ -439,15 +456,18 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(ConvArgs a, int nb_ch, 
     }
 }
 
-template <int KS, int PT>
+template <int KS, int PT, bool HILO = false>
 int launch_pw(const ConvArgs& a, int mode, hipStream_t s) {
+    if constexpr (!HILO) {
+        if (a.w_lo) return launch_pw<KS, PT, true>(a, mode, s);
+    }
     constexpr bool PRE = KS <= 3;
     constexpr int LDS_MAX = 72 * 1024;               // two workgroups per CU
     // row stride in 16-byte chunks == 2 (mod 4), i.e. 32 (mod 64) bytes: ds_read_b128 is serviced in the lane groups
     // {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... over 64 banks, and with the fragment pattern (lane&15 = row, lane>>4 =
     // chunk) that stride puts each group's 16 chunks on 16 distinct 16-byte slots (an ODD chunk stride does not: 46 %
     // conflict cycles measured)
-    int s16 = KS * 4;
+    int s16 = KS * 4 * (HILO ? 2 : 1);
     while ((s16 & 3) != 2) ++s16;
     const int stride = s16 * 16;
     const int cout64 = (a.Cout_g + 63) & ~63;
@@ -466,11 +486,11 @@ int launch_pw(const ConvArgs& a, int mode, hipStream_t s) {
     if (gx > n_tiles) gx = n_tiles;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_kernel<KS, PT, PRE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_kernel<KS, PT, PRE, HILO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         attr_set = true;
     }
-    hipLaunchKernelGGL((pw_gemm_kernel<KS, PT, PRE>), dim3((unsigned)gx, (unsigned)n_chunks), dim3(256),
+    hipLaunchKernelGGL((pw_gemm_kernel<KS, PT, PRE, HILO>), dim3((unsigned)gx, (unsigned)n_chunks), dim3(256),
                        (size_t)nb_ch * (stride + 4), s, a, nb_ch, stride, n_tiles, mode);
     return vip_launch_status("vip_conv2d_nhwc_f16(pw)");
 }
@@ -1073,7 +1093,7 @@ int launch(const ConvArgs& a0, int groups, hipStream_t s) {
 }  // namespace
 
 static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void* w, const float* bias, const void* residual, void* y,
-                       const vip_conv_desc* d, void* stream) {
+                       const vip_conv_desc* d, void* stream, const void* w_lo = nullptr) {
     VIP_REQUIRE(x && w && y && d, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_f16: null pointer");
     VIP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 &&
                     d->sh > 0 && d->sw > 0 && d->Ho > 0 && d->Wo > 0 && d->groups > 0 && d->pt >= 0 && d->pl >= 0,
@@ -1113,6 +1133,7 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
                 "vip_conv2d_nhwc_f16: input or weight tensor exceeds the 4 GiB buffer-addressing range");
     a.act_pre = d->act_pre; a.act_post = d->act_post;
     a.m_blocks = a.n_blocks = 0;
+    a.w_lo = (const f16*)w_lo;
     a.gate = (const f16*)gate;
     a.gate_hw = d->Ho * d->Wo;
     a.y_lo_off = y_lo_off;
@@ -1131,6 +1152,11 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
         if (!residual && d->act_post == VIP_ACT_NONE) mode = d->act_pre;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_NONE) mode = 5;
         else if (residual && d->act_pre == VIP_ACT_NONE && d->act_post == VIP_ACT_RELU) mode = 6;
+        if (w_lo) {     // hi + lo weights: the streaming kernel is the one that carries them (any M)
+            VIP_REQUIRE(mode >= 0 && short_k && !gate && !y_lo_off, VIP_ERR_UNSUPPORTED,
+                        "vip_conv2d_hilo_nhwc_f16: 1x1 stride-1 ungrouped, K <= 256, (activation) or (residual [+ReLU]) epilogue");
+            return launch_pw_k<4>(a, mode, s);
+        }
         if (M <= 256 && !residual && !gate && d->act_post == VIP_ACT_NONE && d->ldy % 4 == 0 && d->cout_off % 4 == 0 &&
             a.x_span_bytes < 0xFFFF0000L - 2L * a.K && 2L * cout_g * d->ldw < 0xFFFF0000L - 2L * a.K) {
             hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)((cout_g + 15) / 16), (unsigned)((M + 63) / 64)), dim3(256), 0, s, a);
@@ -1167,6 +1193,7 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
             d->W < 30000 && d->pt < 16 && d->pl < 16)
             return cout_g <= 64 ? launch_pwk_conv<1>(a, mode, d->groups, s) : launch_pwk_conv<2>(a, mode, d->groups, s);
     }
+    VIP_REQUIRE(!w_lo, VIP_ERR_UNSUPPORTED, "vip_conv2d_hilo_nhwc_f16: only 1x1 stride-1 ungrouped convolutions with K <= 256");
     VIP_REQUIRE(!gate, VIP_ERR_UNSUPPORTED,
                 "vip_conv2d_gated_nhwc_f16: only 1x1 stride-1 ungrouped convolutions with (activation) or (residual [+ReLU]) "
                 "epilogues take a gate; apply vip_scale_add_act_f16 first");
@@ -1185,6 +1212,12 @@ extern "C" int vip_conv2d_gated_nhwc_f16(const void* x, const void* gate, const 
     VIP_REQUIRE(d && d->cin_off == 0 && d->ldx == d->Cin, VIP_ERR_UNSUPPORTED,
                 "vip_conv2d_gated_nhwc_f16: the gate indexes the whole input channel axis (cin_off = 0, ldx = Cin)");
     return conv2d_impl(x, gate, 0, w, bias, residual, y, d, stream);
+}
+
+extern "C" int vip_conv2d_hilo_nhwc_f16(const void* x, const void* w_hi, const void* w_lo, const float* bias,
+                                        const void* residual, void* y, const vip_conv_desc* d, void* stream) {
+    VIP_REQUIRE(w_lo, VIP_ERR_BAD_ARG, "vip_conv2d_hilo_nhwc_f16: null w_lo");
+    return conv2d_impl(x, nullptr, 0, w_hi, bias, residual, y, d, stream, w_lo);
 }
 
 extern "C" int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const void* residual,

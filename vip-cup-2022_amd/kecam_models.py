@@ -45,10 +45,10 @@ def same_pad(size, k, s):
     return total // 2, total - total // 2
 
 
-def _cbn(p, conv, bn, eps, dev, pad_cin=None, conv_bias=None):
+def _cbn(p, conv, bn, eps, dev, pad_cin=None, conv_bias=None, hilo=False):
     w, b = fold_bn(p[f"{conv}conv/kernel"], p[f"{bn}bn/gamma"], p[f"{bn}bn/beta"], p[f"{bn}bn/moving_mean"],
                    p[f"{bn}bn/moving_variance"], eps, conv_bias)
-    return ops.make_conv_weight(w, b, device=dev, pad_cin_to=pad_cin)
+    return ops.make_conv_weight(w, b, device=dev, pad_cin_to=pad_cin, hilo=hilo)
 
 
 def _head(p, dev):
@@ -267,10 +267,15 @@ class EfficientNet(_Base):
         eps = 1e-5 if self.torch_mode else 1e-3
         self.stem = _cbn(p, "stem_", "stem_", eps, dev, pad_cin=8)
         self.blocks = []
+        div = first_strides                               # cumulative stride of the block's input
         for (n, cin, hid, out, st, e, sc, k, red, fused, stage) in _effnet_blocks(c):
             blk = dict(stride=st, expand=e, shortcut=sc, k=k, fused=fused, stage=stage, exp=None, dw=None, se=None)
+            # 1x1 convolutions with Cin <= 256 on the high-resolution stages (input stride <= 8: >= 25 x 25 pixels, i.e. the
+            # HBM-bound streaming-kernel shapes at batch 256) carry two-term weights: their fp16 weight rounding is 2/3 of
+            # EfficientNetV1-B4's weight-induced logit error (Numerics), and there the second MFMA is nearly free
             if e != 1:
-                blk["exp"] = _cbn(p, f"{n}sortcut_", f"{n}sortcut_", eps, dev)
+                blk["exp"] = _cbn(p, f"{n}sortcut_", f"{n}sortcut_", eps, dev, hilo=(div <= 8))
+            div *= st
             if not fused:
                 s_ = p[f"{n}MB_dw_bn/gamma"] / torch.sqrt(p[f"{n}MB_dw_bn/moving_variance"] + eps)
                 b = p[f"{n}MB_dw_bn/beta"] - p[f"{n}MB_dw_bn/moving_mean"] * s_
@@ -283,7 +288,7 @@ class EfficientNet(_Base):
             if fused and e == 1:
                 blk["out"] = _cbn(p, f"{n}fu_", f"{n}fu_", eps, dev)
             else:
-                blk["out"] = _cbn(p, f"{n}MB_pw_", f"{n}MB_pw_", eps, dev)
+                blk["out"] = _cbn(p, f"{n}MB_pw_", f"{n}MB_pw_", eps, dev, hilo=(red == 0 and div <= 8))   # gated (SE) layers cannot
             self.blocks.append(blk)
         self.post = _cbn(p, "post_", "post_", eps, dev)
         self.head_w, self.head_b = _head(p, dev)

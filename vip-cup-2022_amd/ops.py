@@ -56,6 +56,7 @@ class ConvWeight:
     groups: int = 1
     alg_cin_g: int = 0   # un-padded input channels per group (algorithmic FLOP count)
     err: Optional[torch.Tensor] = None   # fp32 [cout, ldw]: (fp32 weight - stored fp16 weight), kept only until calibrate()
+    w_lo: Optional[torch.Tensor] = None  # fp16 [cout, ldw]: fp16(W32 - w) for the two-term-weight kernel (see make_conv_weight)
 
     @property
     def cin(self):
@@ -121,12 +122,24 @@ def diffuse_round_f16(w_rows: torch.Tensor) -> torch.Tensor:
     return q.t().contiguous()
 
 
+HILO_MAX_K = 256     # vip_conv2d_hilo_nhwc_f16: the streaming kernel's K limit
+
+
+def hilo_eligible(kh: int, kw: int, cin: int, groups: int = 1) -> bool:
+    """Can a layer carry two-term weights (w + w_lo)?  1x1, ungrouped, K <= 256 (VIP_HILO=0 switches them off)."""
+    import os
+    return kh == 1 and kw == 1 and groups == 1 and cin <= HILO_MAX_K and os.environ.get("VIP_HILO", "1") != "0"
+
+
 def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], groups: int = 1,
                      device="cuda", pad_cin_to: Optional[int] = None,
-                     pad_cout_to: Optional[int] = None) -> ConvWeight:
+                     pad_cout_to: Optional[int] = None, hilo: bool = False) -> ConvWeight:
     """Keras HWIO kernel ``[kh,kw,Cin_g,Cout]`` (fp32, BN already folded) -> ConvWeight.
     (OIHW->HWIO is the reference's own convention, tfimm/utils/timm.py:164-170.)
-    Optionally zero-pads Cin (e.g. RGB 3 -> 8) and Cout (e.g. a 1-class head -> 8)."""
+    Optionally zero-pads Cin (e.g. RGB 3 -> 8) and Cout (e.g. a 1-class head -> 8).
+    ``hilo``: also keep ``w_lo = fp16(W32 - fp16(W32))``; ``conv2d`` then runs the layer with both terms (~22-bit
+    weights) - for the HBM-bound short-K 1x1 layers whose weight rounding dominates a member's logit error
+    (EfficientNet expand convolutions); only where ``hilo_eligible`` holds, and the layer must not be gated."""
     kh, kw, cin_g, cout = kernel_hwio.shape
     alg_cin_g = cin_g
     k = kernel_hwio.detach().to(torch.float32)
@@ -143,21 +156,29 @@ def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], gr
         cout = pad_cout_to
     # round along (channel, tap): the taps of one input channel see the same mean activation, so their rounding
     # errors are diffused into each other first; the carry then runs on across channels
-    w = diffuse_round_f16(k.permute(3, 2, 0, 1).reshape(cout, cin_g * kh * kw))
-    w = w.reshape(cout, cin_g, kh, kw).permute(0, 2, 3, 1).reshape(cout, kh * kw * cin_g)
+    hilo = hilo and hilo_eligible(kh, kw, cin_g * groups, groups)
+    if hilo:    # plain round-to-nearest high part; the low part carries what it misses
+        w = k.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin_g).to(torch.float16)
+    else:
+        w = diffuse_round_f16(k.permute(3, 2, 0, 1).reshape(cout, cin_g * kh * kw))
+        w = w.reshape(cout, cin_g, kh, kw).permute(0, 2, 3, 1).reshape(cout, kh * kw * cin_g)
     ktot = w.shape[1]
     ldw = (ktot + 7) // 8 * 8
     if ldw != ktot:
         w = torch.cat([w, w.new_zeros(cout, ldw - ktot)], dim=1)
-    err = None
-    if KEEP_ROUNDING_ERROR:
+    err, w_lo = None, None
+    if KEEP_ROUNDING_ERROR or hilo:
         w32 = k.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin_g)
         if ldw != ktot:
             w32 = torch.cat([w32, w32.new_zeros(cout, ldw - ktot)], dim=1)
-        err = (w32 - w.to(torch.float32)).to(device).contiguous()
+        resid = w32 - w.to(torch.float32)
+        if hilo:                                   # nothing left for the bias calibration to correct
+            w_lo = resid.to(torch.float16).to(device).contiguous()
+        else:
+            err = resid.to(device).contiguous()
     return ConvWeight(w=w.to(device=device, dtype=torch.float16).contiguous(),
                       bias=None if b is None else b.to(device).contiguous(),
-                      kh=kh, kw=kw, cin_g=cin_g, cout=cout, groups=groups, alg_cin_g=alg_cin_g, err=err)
+                      kh=kh, kw=kw, cin_g=cin_g, cout=cout, groups=groups, alg_cin_g=alg_cin_g, err=err, w_lo=w_lo)
 
 
 def make_dense_weight(kernel_io: torch.Tensor, bias: Optional[torch.Tensor], device="cuda",
@@ -226,9 +247,16 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
                                 act, act_post, residual is not None, cw.cin_g)
         if gate is not None:
             name = "pwk_gemm_kernel"
+        if cw.w_lo is not None:
+            name = "pw_gemm_kernel"
         tok = _PROF.start(name, 2.0 * M * cw.cout * kk,
                           2.0 * (B * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()))
-    if gate is not None:
+    if cw.w_lo is not None:
+        if gate is not None:
+            raise _abi.VipError("conv2d: a two-term-weight layer cannot take a gate")
+        st = _abi.lib().vip_conv2d_hilo_nhwc_f16(_p(x), _p(cw.w), _p(cw.w_lo), _p(cw.bias), _p(residual), _p(out),
+                                                 C.byref(d), _stream())
+    elif gate is not None:
         st = _abi.lib().vip_conv2d_gated_nhwc_f16(_p(x), _p(gate), _p(cw.w), _p(cw.bias), _p(residual), _p(out),
                                                   C.byref(d), _stream())
     else:
