@@ -125,10 +125,11 @@ class ResNest(_Base):
                 n = f"stack{si + 1}_block{bi + 1}_"
                 s = st if bi == 0 else 1
                 blk = {"stride": s, "hid": hid, "sc": None}
+                hl = si <= 1                       # two-term weights on the >= 25 x 25-pixel stages (K <= 256 layers only)
                 if bi == 0 and (s != 1 or cin != oc):
-                    blk["sc"] = _cbn(p, f"{n}shortcut_", f"{n}shortcut_", eps, dev)
-                blk["d1"] = _cbn(p, f"{n}deep_1_", f"{n}deep_1_", eps, dev)
-                blk["d3"] = _cbn(p, f"{n}deep_3_", f"{n}3_", eps, dev)
+                    blk["sc"] = _cbn(p, f"{n}shortcut_", f"{n}shortcut_", eps, dev, hilo=hl)
+                blk["d1"] = _cbn(p, f"{n}deep_1_", f"{n}deep_1_", eps, dev, hilo=hl)
+                blk["d3"] = _cbn(p, f"{n}deep_3_", f"{n}3_", eps, dev, hilo=hl)
                 if cfg.get("attn", "sa") is None:                       # ResNetD: conv3x3 (stride here) + BN + ReLU
                     blk["d2"] = _cbn(p, f"{n}deep_2_", f"{n}deep_2_", eps, dev)
                     self.blocks.append(blk)

@@ -78,10 +78,10 @@ class ResNetRS:
         self.has_se = 0 < se_ratio < 1
         p = params
 
-        def cbn(conv, bn, pad_cin=None):
+        def cbn(conv, bn, pad_cin=None, hilo=False):
             w, b = fold_bn(p[f"{conv}/kernel"], p[f"{bn}/gamma"], p[f"{bn}/beta"], p[f"{bn}/moving_mean"],
                            p[f"{bn}/moving_variance"], bn_epsilon)
-            return ops.make_conv_weight(w, b, device=device, pad_cin_to=pad_cin)
+            return ops.make_conv_weight(w, b, device=device, pad_cin_to=pad_cin, hilo=hilo)
 
         self.stem = [cbn(f"stem_conv_{i}", f"stem_batch_norm_{i}", 8 if i == 1 else None) for i in range(1, 5)]
         self.blocks = []
@@ -89,11 +89,14 @@ class ResNetRS:
             for bi in range(reps):
                 n = f"c{gi + 2}_block_{bi}_"
                 blk = {"stride": (1 if gi == 0 else 2) if bi == 0 else 1, "proj": None}
+                # the 1x1 convolutions of the two high-resolution groups (>= 25 x 25 pixels) with K <= 256 carry two-term
+                # weights (HBM-bound streaming-kernel shapes; see ops.make_conv_weight / DESIGN.md Numerics)
+                hl = gi <= 1
                 if bi == 0:
-                    blk["proj"] = cbn(n + "projection_conv", n + "projection_batch_norm")
-                blk["c1"] = cbn(n + "conv_1", n + "batch_norm_1")
+                    blk["proj"] = cbn(n + "projection_conv", n + "projection_batch_norm", hilo=hl)
+                blk["c1"] = cbn(n + "conv_1", n + "batch_norm_1", hilo=hl)
                 blk["c2"] = cbn(n + "conv_2", n + "batch_norm_2")
-                blk["c3"] = cbn(n + "conv_3", n + "batch_norm_3")
+                blk["c3"] = cbn(n + "conv_3", n + "batch_norm_3", hilo=hl)
                 if self.has_se:
                     blk["se_r"] = ops.make_conv_weight(p[n + "se_reduce/kernel"], p[n + "se_reduce/bias"], device=device)
                     blk["se_e"] = ops.make_conv_weight(p[n + "se_expand/kernel"], p[n + "se_expand/bias"], device=device)
