@@ -84,3 +84,25 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_abi, "LIB_PATH", "/nonexistent/libvipcup_hip.so")
     with pytest.raises(_abi.VipError):
         _abi.lib()
+
+
+def test_product_fails_loudly_without_library_or_gpu(monkeypatch):
+    """No CPU fallback anywhere: a missing .so raises on first use, and the CLI / bench refuse to start without a GPU."""
+    import subprocess
+    import sys
+    import pytest
+    import torch
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import _abi
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setattr(_abi, "LIB_PATH", os.path.join(os.path.dirname(_abi.LIB_PATH), "no_such_library.so"))
+    with pytest.raises(_abi.VipError, match="no CPU fallback"):
+        _abi.lib()
+    monkeypatch.undo()
+    assert _abi.lib() is not None
+    if not torch.cuda.is_available():
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for cmd in ([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                    [sys.executable, os.path.join(root, "vip-cup-2022_amd", "main.py"), "in.csv", "out.csv", "--synthetic"]):
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd=root, timeout=300)
+            assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout), (cmd, r.stderr[-500:])
