@@ -6,8 +6,8 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
-HBM: preprocessed fp16 NHWC images -> forward of every ensemble member the rank owns -> per-image scores
-(-> RCCL all-gather of the scores when N > 1).  Scaling is weak: every rank scores its own batch of
+HBM: decoded 200x200 RGB u8 images (what tf.image.decode_jpeg yields) -> bicubic resize + /255 per member resolution ->
+forward of every ensemble member -> ensemble-mean scores (-> RCCL all-gather of the scores when N > 1).  Scaling is weak: every rank scores its own batch of
 `--batch` images with all members (image-parallel sharding, SURVEY.md §8e second form), so
 value = N * batch * K / t.
 
