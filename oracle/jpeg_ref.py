@@ -417,6 +417,10 @@ def decode_rgb(data: bytes) -> np.ndarray:
         dw, dh = -(-W * c["h"] // hmax), -(-H * c["v"] // vmax)
         if hs == 1 and vs == 1:
             u = pl
+        elif hs == 2 and dw <= 2:
+            # jdsample.c jinit_upsampler: the fancy (triangle) filters are only chosen when downsampled_width > 2;
+            # narrower planes get h2v1_upsample / h2v2_upsample, plain replication
+            u = np.repeat(np.repeat(pl[:dh, :dw], 2, axis=1), vs, axis=0)
         elif hs == 2 and vs == 1:
             u = _h2v1(pl, dw)
         elif hs == 2 and vs == 2:

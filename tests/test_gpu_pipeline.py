@@ -96,6 +96,9 @@ def test_tiny_gray_and_odd_images_through_decode_and_resize(report):
     raws = []
     for hw, mode, kw in (((1, 1), "RGB", dict(quality=90)), ((3, 5), "RGB", dict(quality=75, subsampling=2)),
                          ((17, 13), "L", dict(quality=80)), ((9, 31), "RGB", dict(quality=60, subsampling=1, progressive=True)),
+                         # chroma planes <= 2 samples wide: libjpeg-turbo replicates instead of fancy-upsampling (jdsample.c)
+                         ((20, 4), "RGB", dict(quality=95, subsampling=1)), ((16, 3), "RGB", dict(quality=77, subsampling=2)),
+                         ((9, 2), "RGB", dict(quality=30, subsampling=2)), ((8, 1), "RGB", dict(quality=95, subsampling=2)),
                          ((200, 200), "RGB", dict(quality=85))):
         b = io.BytesIO()
         Image.fromarray(px[:hw[0], :hw[1]]).convert(mode).save(b, format="JPEG", **kw)

@@ -129,3 +129,41 @@ def test_unsupported_streams_are_rejected():
     raw[i + 6] = 0x70                                     # SOS selects DC table 7
     with pytest.raises(_abi.VipError):
         pipeline.entropy_decode([bytes(raw)])
+
+
+def test_host_decoder_matches_oracle_and_pillow_on_random_small_images():
+    """40 random encodings (size 1..48, quality 5..100, 4:4:4 / 4:2:2 / 4:2:0 / gray, baseline / progressive / optimised
+    tables / restart intervals): host coefficients == oracle coefficients, oracle pixels == libjpeg-turbo pixels."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import pipeline
+    rng = np.random.default_rng(20221)
+    raws = []
+    for i in range(40):
+        h, w = int(rng.integers(1, 49)), int(rng.integers(1, 49))
+        smooth = rng.integers(0, 256, size=(max(1, h // 6) + 1, max(1, w // 6) + 1, 3))
+        img = np.kron(smooth, np.ones((6, 6, 1)))[:h, :w] + rng.normal(0, 10, (h, w, 3))
+        im = Image.fromarray(np.clip(img, 0, 255).astype(np.uint8))
+        kw = dict(quality=int(rng.integers(5, 101)))
+        mode = int(rng.integers(0, 4))
+        if mode == 3:
+            im = im.convert("L")
+        else:
+            kw["subsampling"] = mode
+        if rng.random() < 0.4:
+            kw["progressive"] = True
+        if rng.random() < 0.3:
+            kw["optimize"] = True
+        if rng.random() < 0.3:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 5))
+        b = io.BytesIO()
+        im.save(b, format="JPEG", **kw)
+        raws.append(b.getvalue())
+    desc, coef = pipeline.entropy_decode(raws, threads=2)
+    for i, raw in enumerate(raws):
+        P = jpeg_ref.parse(raw)
+        ref_coefs, _ = jpeg_ref.entropy_decode(P)
+        d = desc[i]
+        for c, rc in enumerate(ref_coefs):
+            got = coef[d.coef_off[c]:d.coef_off[c] + rc.size].reshape(rc.shape)
+            assert np.array_equal(got.astype(np.int64), rc), (i, c)
+        assert np.array_equal(jpeg_ref.decode_rgb(raw), _pil(raw)), i

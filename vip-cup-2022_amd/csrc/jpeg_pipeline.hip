@@ -128,6 +128,8 @@ __device__ __forceinline__ int chroma_at(const uint8_t* __restrict__ pl, int str
                                          int y, int x) {
     // hs/vs = luma/chroma ratio (1 or 2)
     if (hs == 1 && vs == 1) return pl[(long)y * stride + x];
+    // jdsample.c jinit_upsampler: h2v1 / h2v2 planes no wider than 2 samples get plain replication, not the fancy filter
+    if (hs == 2 && dw <= 2) return pl[(long)(vs == 2 ? y >> 1 : y) * stride + (x >> 1)];
     if (hs == 2 && vs == 1) {  // h2v1_fancy_upsample
         const uint8_t* row = pl + (long)y * stride;
         const int i = x >> 1;
