@@ -250,6 +250,8 @@ typedef struct vip_jpeg_desc {
     int32_t blocks_w[3], blocks_h[3]; /* coefficient-plane size in 8x8 blocks (padded to MCUs)  */
     int64_t coef_off[3];              /* offset (int16 elements) of each component's blocks     */
     uint16_t qt[3][64];               /* dequantisation tables, natural (row-major) order       */
+    int32_t rgb_coded;                /* 3 components that ARE R,G,B (Adobe APP14 transform 0 / ids 'R','G','B',
+                                         libjpeg jdapimin.c default_decompress_parms): no YCbCr->RGB conversion   */
 } vip_jpeg_desc;
 
 /* Host: parse headers only (fills the descriptor; coef_off relative to 0) and report how many int16

@@ -95,6 +95,10 @@ def parse(data: bytes):
             break
         ln = (d[pos] << 8) | d[pos + 1]
         s = d[pos + 2:pos + ln]
+        if m == 0xE0 and bytes(s[:5]) == b"JFIF\x00":
+            P["jfif"] = True
+        if m == 0xEE and len(s) >= 12 and bytes(s[:5]) == b"Adobe":
+            P["adobe_transform"] = s[11]
         if m in (0xC0, 0xC1, 0xC2):
             P["progressive"] = (m == 0xC2)
             assert s[0] == 8
@@ -428,6 +432,15 @@ def decode_rgb(data: bytes) -> np.ndarray:
         else:
             u = _h1v2(pl, dw, dh)
         ch.append(u[:H, :W] - 128)
+    # colour space of a 3-component file as libjpeg guesses it (jdapimin.c default_decompress_parms)
+    rgb_coded = False
+    if not P.get("jfif"):
+        if "adobe_transform" in P:
+            rgb_coded = P["adobe_transform"] == 0
+        else:
+            rgb_coded = [c["id"] for c in P["comp"]] == [ord("R"), ord("G"), ord("B")]
+    if rgb_coded:                                       # null conversion (jdcolor.c rgb_rgb_convert)
+        return np.stack([Y, ch[0] + 128, ch[1] + 128], -1).astype(np.uint8)
     cb, cr = ch
     R = np.clip(Y + ((91881 * cr + 32768) >> 16), 0, 255)
     B = np.clip(Y + ((116130 * cb + 32768) >> 16), 0, 255)

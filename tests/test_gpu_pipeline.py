@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import jpeg_ref  # noqa: E402
 from oracle import ops_ref as R  # noqa: E402
-from tests.test_oracle_jpeg import GOLD, _progressive, _variants  # noqa: E402
+from tests.test_oracle_jpeg import GOLD, _progressive, _rgb_coded, _variants  # noqa: E402
 from tools.make_synth import synth_jpeg  # noqa: E402
 
 
@@ -21,7 +21,7 @@ def _pil(b):
 
 
 def _raws():
-    raws = [synth_jpeg(i) for i in range(12)] + [synth_jpeg(49)] + list(_variants().values()) + list(_progressive().values())
+    raws = [synth_jpeg(i) for i in range(12)] + [synth_jpeg(49)] + list(_variants().values()) + list(_progressive().values()) + list(_rgb_coded().values())
     for n in ("dog_cat", "cat", "dog"):
         raws.append(open(os.path.join(GOLD, f"ref_{n}.jpg"), "rb").read())
     return raws

@@ -36,6 +36,18 @@ def _variants():
     return out
 
 
+def _rgb_coded():
+    """files whose three components ARE R, G, B (Adobe APP14, transform 0) - libjpeg applies no colour conversion"""
+    px = synth_pixels(9)
+    out = {}
+    for name, hw, q in (("rgb_64", (64, 64), 90), ("rgb_33x21", (33, 21), 60), ("rgb_5x3", (5, 3), 75)):
+        b = io.BytesIO()
+        Image.fromarray(px[:hw[0], :hw[1]]).save(b, format="JPEG", quality=q, keep_rgb=True)
+        out[name] = b.getvalue()
+        assert b"Adobe" in out[name]
+    return out
+
+
 def _progressive():
     """progressive (SOF2) encodings: libjpeg's default scan script has DC first/refine, AC first/refine scans,
     interleaved DC scans and per-component AC scans"""
@@ -88,6 +100,16 @@ def test_oracle_matches_pillow_on_synthetic_set():
 def test_oracle_matches_pillow_on_progressive_streams():
     for name, raw in _progressive().items():
         assert np.array_equal(jpeg_ref.decode_rgb(raw), _pil(raw)), name
+
+
+def test_rgb_coded_files_skip_the_colour_conversion():
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import pipeline
+    raws = _rgb_coded()
+    for name, raw in raws.items():
+        assert np.array_equal(jpeg_ref.decode_rgb(raw), _pil(raw)), name
+    desc, _ = pipeline.entropy_decode(list(raws.values()) + [synth_jpeg(0)])
+    assert [d.rgb_coded for d in desc] == [1, 1, 1, 0]
 
 
 def test_host_entropy_decoder_matches_oracle():

@@ -30,7 +30,7 @@ class JpegDesc(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("ncomp", C.c_int32),
                 ("hsamp", C.c_int32 * 3), ("vsamp", C.c_int32 * 3),
                 ("blocks_w", C.c_int32 * 3), ("blocks_h", C.c_int32 * 3),
-                ("coef_off", C.c_int64 * 3), ("qt", (C.c_uint16 * 64) * 3)]
+                ("coef_off", C.c_int64 * 3), ("qt", (C.c_uint16 * 64) * 3), ("rgb_coded", C.c_int32)]
 
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t

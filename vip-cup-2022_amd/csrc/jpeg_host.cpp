@@ -71,6 +71,9 @@ struct Scan {
 
 struct Parsed {
     bool progressive = false;
+    bool saw_jfif = false, saw_adobe = false;
+    int adobe_transform = 0;
+    bool rgb_coded = false;   // 3 components stored as R,G,B (jdapimin.c default_decompress_parms)
     std::vector<Scan> scans;  // filled for progressive and multi-scan sequential files
     int width = 0, height = 0, ncomp = 0;
     Component comp[3];
@@ -111,6 +114,11 @@ int parse(const uint8_t* d, size_t n, Parsed& P, bool need_scan) {
         }
         const uint8_t* s = d + pos + 2;
         const int sl = len - 2;
+        if (m == 0xE0 && sl >= 5 && memcmp(s, "JFIF\0", 5) == 0) P.saw_jfif = true;
+        if (m == 0xEE && sl >= 12 && memcmp(s, "Adobe", 5) == 0) {
+            P.saw_adobe = true;
+            P.adobe_transform = s[11];
+        }
         if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
             P.progressive = (m == 0xC2);
             if (sl < 6 || s[0] != 8) {
@@ -274,6 +282,12 @@ void fill_desc(const Parsed& P, vip_jpeg_desc* d, size_t* elems) {
     d->width = P.width;
     d->height = P.height;
     d->ncomp = P.ncomp;
+    // colour space of a 3-component file, as libjpeg guesses it (jdapimin.c:default_decompress_parms): JFIF -> YCbCr;
+    // else Adobe transform 0 -> RGB, 1 -> YCbCr; else component ids 'R','G','B' -> RGB; anything else YCbCr
+    if (P.ncomp == 3 && !P.saw_jfif) {
+        if (P.saw_adobe) d->rgb_coded = (P.adobe_transform == 0);
+        else d->rgb_coded = (P.comp[0].id == 'R' && P.comp[1].id == 'G' && P.comp[2].id == 'B');
+    }
     size_t off = 0;
     for (int c = 0; c < P.ncomp; ++c) {
         d->hsamp[c] = P.comp[c].h;

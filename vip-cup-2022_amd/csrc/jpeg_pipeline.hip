@@ -173,12 +173,18 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const uint8_t* __restri
         const int hs = d.hsamp[0] / d.hsamp[1], vs = d.vsamp[0] / d.vsamp[1];
         const int dw = (d.width * d.hsamp[1] + d.hsamp[0] - 1) / d.hsamp[0];
         const int dh = (d.height * d.vsamp[1] + d.vsamp[0] - 1) / d.vsamp[0];
-        const int cb = chroma_at(planes + d.coef_off[1], d.blocks_w[1] * 8, dw, dh, hs, vs, y, x) - 128;
-        const int cr = chroma_at(planes + d.coef_off[2], d.blocks_w[2] * 8, dw, dh, hs, vs, y, x) - 128;
-        // jdcolor.c build_ycc_rgb_table: SCALEBITS = 16, ONE_HALF = 32768
-        R = clamp255(Y + ((91881 * cr + 32768) >> 16));
-        B = clamp255(Y + ((116130 * cb + 32768) >> 16));
-        G = clamp255(Y + ((-22554 * cb + 32768 + (-46802) * cr) >> 16));
+        const int c1 = chroma_at(planes + d.coef_off[1], d.blocks_w[1] * 8, dw, dh, hs, vs, y, x);
+        const int c2 = chroma_at(planes + d.coef_off[2], d.blocks_w[2] * 8, dw, dh, hs, vs, y, x);
+        if (d.rgb_coded) {                 // the planes are R, G, B already (Adobe transform 0): null colour conversion
+            G = c1;
+            B = c2;
+        } else {
+            const int cb = c1 - 128, cr = c2 - 128;
+            // jdcolor.c build_ycc_rgb_table: SCALEBITS = 16, ONE_HALF = 32768
+            R = clamp255(Y + ((91881 * cr + 32768) >> 16));
+            B = clamp255(Y + ((116130 * cb + 32768) >> 16));
+            G = clamp255(Y + ((-22554 * cb + 32768 + (-46802) * cr) >> 16));
+        }
     }
     uint8_t* o = rgb + (((long)blockIdx.z * maxH + y) * maxW + x) * 3;
     o[0] = (uint8_t)R;
