@@ -7,7 +7,7 @@ import subprocess
 
 import pytest
 
-from tests.test_oracle_jpeg import _progressive, _variants
+from tests.test_oracle_jpeg import _progressive, _rgb_coded, _variants
 from tools.make_synth import synth_jpeg
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +22,7 @@ def test_host_decoder_survives_mutated_streams(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     files = []
-    corpus = {"synth0": synth_jpeg(0), "synth49": synth_jpeg(49), **_variants(), **_progressive()}
+    corpus = {"synth0": synth_jpeg(0), "synth49": synth_jpeg(49), **_variants(), **_progressive(), **_rgb_coded()}
     for name, raw in corpus.items():
         p = tmp_path / f"{name}.jpg"
         p.write_bytes(raw)
@@ -32,4 +32,4 @@ def test_host_decoder_survives_mutated_streams(tmp_path):
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-4000:])
     assert "fuzzed" in r.stdout
     n_total, n_ok = int(r.stdout.split()[1]), int(r.stdout.split()[3])
-    assert n_total > 5000 and 0 < n_ok < n_total          # some mutations still decode, most are rejected or cut short
+    assert n_total > 6000 and 0 < n_ok < n_total          # some mutations still decode, most are rejected or cut short
