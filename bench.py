@@ -3,18 +3,26 @@
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--shard images|members|hybrid]
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
-HBM: decoded 200x200 RGB u8 images (what tf.image.decode_jpeg yields) -> bicubic resize + /255 per member resolution ->
-forward of every ensemble member -> ensemble-mean scores (-> RCCL all-gather of the scores when N > 1).  Scaling is weak: every rank scores its own batch of
-`--batch` images with all members (image-parallel sharding, SURVEY.md §8e second form), so
-value = N * batch * K / t.
+Default workload = BASELINE.json config 5 ("ensemble8": the seven manifest members + tfimm ViT-S/16).  A "step" is one pass of the
+hot path over one batch of synthetic input per rank, starting at the JPEG BYTES ("bytes in RAM -> scores"):
+256 synthetic 200x200 JPEG byte strings resident in host RAM -> host Huffman decode into a page-locked buffer (C++ threads; one batch
+of read-ahead on a worker thread, the overlap tf.data's prefetch gives the reference, dataset/dataset.py:101) -> H2D -> GPU dequant /
+IDCT / upsample / YCbCr->RGB -> bicubic resize + /255 per member resolution -> forward of every ensemble member -> ONE RCCL all-gather
+of the scores when N > 1 -> ensemble mean.  Scaling is weak: every rank brings its own batch of `--batch` images (one image-shard
+per rank); `--shard` picks how the (member, image-shard) grid is dealt to the ranks (vipcup_amd/ensemble.py ShardPlan), the default
+`images` keeps every member on every rank.  value = N * batch * K / t.
+
+The round-1 variant (the step starts from decoded RGB u8 pixels already resident in HBM: the metric's "inputs resident" form) is
+`--workload ensemble8-resident`; the default run times it as well and reports it under "detail".
 
 Extra objects on the JSON line:
-  roofline     — the dominant kernel family, timed live with HIP events on the launch stream;
-  cpu_baseline — the fp32 CPU oracle ("port": the reference's TF path cannot run anywhere here) on a
-                 bounded sample of the same workload, rank 0, N = 1 only.
+  roofline     — the dominant kernel family, timed live with HIP events on the launch stream; `peak` is the vendor figure of
+                 MI355X_MICROARCH.md, `peak_measured` the on-box probe (vip_microbench_*), both fractions are given;
+  cpu_baseline — the fp32 CPU oracle ("port": the reference's TF path cannot run anywhere here) on a bounded sample of the same
+                 workload with the protocol of SURVEY.md section 8(d) (batch 128, first batch discarded, >= 3 timed batches, all host
+                 cores of the box's share, Pillow decode + oracle resize + every member), rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -27,8 +35,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_MFMA_F16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak
-PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+PEAK_MFMA_F16_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak (vendor)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak (vendor)
 
 
 def parse():
@@ -37,37 +45,83 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--workload", default="auto", help="auto | resnet_rs50 | gcvit_tiny | ensemble")
+    ap.add_argument("--workload", default="auto",
+                    help="auto (= ensemble8) | ensemble8 | ensemble (7 manifest members) | ensemble4 | <member name>; "
+                         "suffix -resident: start from decoded pixels in HBM")
+    ap.add_argument("--shard", default="images", choices=["images", "members", "hybrid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=32)
+    ap.add_argument("--cpu-batches", type=int, default=3, help="timed CPU batches of 128 images (after one discarded)")
+    ap.add_argument("--no-resident-leg", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(wl, n_images):
-    """The fp32 CPU oracle (oracle/*, a port — the reference's TF/Keras path cannot run here) timed on the
-    host cores over a bounded sample of the same workload: n_images images through every member,
-    batch 16, first batch discarded (protocol of tfimm/utils/profile.py:30-42)."""
+def host_cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(wl, timed_batches: int):
+    """SURVEY.md section 8(d) protocol with the fp32 CPU oracle (oracle/*: a port - the reference's TF/Keras path cannot run here):
+    the same synthetic JPEGs, batch 128 (the reference's batch, main.py:85), first batch discarded, `timed_batches` >= 3 timed batches,
+    torch threads = every host core this process may use; per batch: Pillow (libjpeg-turbo) decode -> oracle bicubic resize + /255 per
+    member resolution -> every member's oracle forward (the reference re-decodes per member, main.py:67,89 - decode is counted once
+    per member resolution here, in its favour)."""
     import importlib
+    import io
+    import numpy as np
+    from PIL import Image
+    from oracle import ops_ref as R
     from vipcup_amd import zoo
-    threads = min(16, os.cpu_count() or 1)  # the GPU box gives one GPU a 16-core share
+    threads = host_cores()
     torch.set_num_threads(threads)
-    bs = 16
-    total_s = 0.0
-    g = torch.Generator().manual_seed(99)
-    for name in wl.members:
-        spec = zoo.MEMBERS[name]
-        ref = importlib.import_module(f"oracle.{spec.oracle}")
-        params = zoo.build_params(name)
-        x = torch.rand((bs, spec.input_hw, spec.input_hw, 3), generator=g)
+    bs = 128
+    raws = (wl.jpegs * (bs // len(wl.jpegs) + 1))[:bs]
+    params = {m: zoo.build_params(m) for m in wl.members}
+    refs = {m: importlib.import_module(f"oracle.{zoo.MEMBERS[m].oracle}") for m in wl.members}
+
+    def one_batch():
+        pix = [np.asarray(Image.open(io.BytesIO(r)).convert("RGB")) for r in raws]
+        inputs = {}
+        for m in wl.members:
+            hw = zoo.MEMBERS[m].input_hw
+            if hw not in inputs:
+                inputs[hw] = torch.stack([R.decode_resize_normalize(p, hw, hw) for p in pix])
         with torch.no_grad():
-            ref.predict_logits(name, params, x)  # discarded
-            t0 = time.perf_counter()
-            for _ in range(max(1, n_images // bs)):
-                ref.predict_logits(name, params, x)
-            total_s += time.perf_counter() - t0
-    n = max(1, n_images // bs) * bs
-    return {"value": n / total_s, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"{n} synthetic images x {len(wl.members)} member(s), batch {bs}, fp32 torch-CPU oracle"}
+            for m in wl.members:
+                refs[m].predict_logits(m, params[m], inputs[zoo.MEMBERS[m].input_hw])
+
+    one_batch()                                  # discarded (tfimm/utils/profile.py:30-42)
+    t0 = time.perf_counter()
+    for _ in range(timed_batches):
+        one_batch()
+    dt = time.perf_counter() - t0
+    return {"value": timed_batches * bs / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"{timed_batches} timed batches of {bs} synthetic JPEGs (1 discarded) x {len(wl.members)} members: Pillow decode + "
+                      f"oracle resize + fp32 torch-CPU oracle forward, {threads} threads",
+            "seconds": dt}
+
+
+def timed_steps(wl, dist, steps, warmup):
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        wl.step(dist)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step(dist)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
 
 
 def main():
@@ -96,30 +150,26 @@ def main():
     from vipcup_amd import workloads
 
     name = a.workload if a.workload != "auto" else workloads.DEFAULT
-    wl = workloads.build(name, batch=a.batch, rank=rank, world=world)
+    wl = workloads.build(name, batch=a.batch, rank=rank, world=world, shard=a.shard)
+    dt = timed_steps(wl, dist, a.steps, a.warmup)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    # the metric's "inputs already resident in HBM" form of the same step, for the record (never `value` here)
+    resident = None
+    if not wl.resident and not a.no_resident_leg:
+        wr = workloads.Workload(wl.name, wl.members, a.batch, rank, world, a.shard, resident=True, jpegs=wl.jpegs, models=wl.models)
+        wr.member_streams = wl.member_streams                                # same resident members, same stream assignment
+        dtr = timed_steps(wr, dist, a.steps, 1)
+        resident = {"images_per_sec": a.batch * world * a.steps / dtr, "ms_per_step": dtr / a.steps * 1e3,
+                    "input": "decoded RGB u8 resident in HBM (no Huffman / H2D / IDCT in the step)"}
 
-    for _ in range(a.warmup):
-        wl.step(dist)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wl.step(dist)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    roof = wl.roofline(PEAK_MFMA_F16_TFLOPS, PEAK_HBM_GBS) if rank == 0 else None
+    roof, peaks = None, None
+    if rank == 0:
+        peaks = {"mfma_tflops": PEAK_MFMA_F16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS}
+        peaks.update(workloads.measure_peaks())
+        roof = wl.roofline(peaks)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(wl, a.cpu_images)
+        cpu = cpu_baseline(wl, max(3, a.cpu_batches))
 
     if rank == 0:
         images = a.batch * world * a.steps
@@ -140,10 +190,14 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        extra = wl.extra()
-        if extra:
-            line["detail"] = extra
+        detail = {"kernel_families": wl.extra(), "resident_input_variant": resident,
+                  "peaks": {"vendor": {"mfma_f16_tflops": PEAK_MFMA_F16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS},
+                            "measured_on_box": {k: round(v, 1) for k, v in peaks.items() if k.endswith("_measured")}}}
+        if world > 1:
+            detail["shard_plan"] = wl.plan.describe()
+        line["detail"] = detail
         print(json.dumps(line))
+    wl.close()
     if dist is not None:
         dist.barrier()                      # rank 0 is still in its instrumented step / JSON line: leave together
         dist.destroy_process_group()

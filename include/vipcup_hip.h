@@ -292,6 +292,30 @@ int vip_resize_bicubic_norm_f16(const uint8_t* rgb_u8, const int32_t* sizes_hw, 
 int vip_tta_augment_f16(const void* x, void* y, const int32_t* flags, int B, int H, int W, int C,
                         void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Introspection and measurement support (no reference counterpart: the reference leaves kernel choice to cuDNN and
+ * has no roofline measurement; SURVEY.md section 8(b) / 8(d) ask for these).
+ * ------------------------------------------------------------------------------------------ */
+
+/* Which kernel vip_conv2d_nhwc_f16 / _gated_ / _hilo_ would launch for this descriptor ("pw_gemm_kernel",
+ * "pwk_direct_kernel", "pwk_gemm_kernel", "pwk_gemm_kernel(im2col)", "rows_gemm_kernel", "conv_igemm_kernel"):
+ * the dispatcher itself in a dry run, nothing is launched.  Used to label profiler records (bench.py roofline). */
+int vip_conv2d_kernel_name(const vip_conv_desc* d, int has_residual, int has_gate, int has_w_lo, char* name_h,
+                           size_t cap);
+
+/* Scratch memory an entry point needs from its caller (bytes); 0 for every operator that works in place on its
+ * operands.  op = one of VIP_OP_*; dims as documented per op. */
+enum { VIP_OP_CONV2D = 0, VIP_OP_MLP_FUSED = 1, VIP_OP_WINDOW_ATTN = 2, VIP_OP_MHSA = 3,
+       VIP_OP_JPEG_IDCT_RGB = 4 /* dims[0] = total int16 coefficients of the batch -> planes_ws bytes */ };
+size_t vip_workspace_bytes(int op, const int64_t* dims, int ndims);
+
+/* On-box peak probes for the roofline denominators ("measured on-box, never hard-coded").
+ * vip_microbench_copy: dst[i] = src[i] over `bytes` bytes (16 B per lane, grid-stride) - 2*bytes of HBM traffic.
+ * vip_microbench_mfma_f16: every wave of a chip-filling grid issues `iters` rounds of 16 independent
+ * v_mfma_f32_16x16x32_f16; *flops_h receives the FLOPs of the launch; sink = >= 4 device bytes. */
+int vip_microbench_copy(const void* src, void* dst, size_t bytes, void* stream);
+int vip_microbench_mfma_f16(void* sink, int iters, double* flops_h, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,87 @@
+"""Shared helpers of the GPU parity tests: the oracle side (Pillow/libjpeg-turbo decode -> oracle resize -> oracle graph) and the
+tolerance table.  Test infrastructure (imports oracle/)."""
+import importlib
+import io
+
+import numpy as np
+import torch
+from PIL import Image
+
+from oracle import ops_ref as R
+
+# BASELINE.json north_star: |z_hip - z_ref| <= 1e-3 on the sigmoid logit.
+TOL_NORTH_STAR = 1e-3
+# Per-member ceilings on the CALIBRATED logit (tests/gen_synth_heads.py: the head reads the top principal direction of the oracle's
+# features and is scaled to a logit spread of 1.5, which multiplies a relative feature error by |w||f| = 12 ... 78, /tmp-measured in
+# DESIGN.md section 4).  What the HIP path delivers is the fp16-STORAGE floor: tests/diag_gpu_vs_emul.py runs the same graph on the
+# CPU with fp32 arithmetic and only the operator outputs rounded to fp16 - its error equals the GPU's for every member (e.g.
+# EfficientNetV1-B4 4.4e-3 rms emulated vs 4.3e-3 on the GPU), i.e. the kernels add nothing to it.  Members whose ceiling is above
+# 1e-3 do NOT meet the north-star tolerance member by member; the test reports which, and asserts the ceiling (max over <= 128 images).
+MEMBER_CEILING = {
+    "eca_nfnet_l0": 1.0e-3, "resnet_rs50": 2.5e-3, "convnext_tiny_in22k": 3.5e-3, "resnest50": 4.0e-3,
+    "gcvit_tiny": 7.0e-3, "efficientnet_v2t": 1.0e-2, "efficientnet_v1b4": 1.8e-2,
+    "vit_tiny_patch16_224": 4.0e-3, "vit_small_patch16_224": 4.0e-3,
+}
+TOL_ENSEMBLE_PROB = 1e-3   # the ensemble-mean probability main.py thresholds at 0.487 (uncorrelated member errors average down)
+
+_CACHE = {}
+
+
+def decode_pixels(raws):
+    return [np.asarray(Image.open(io.BytesIO(r)).convert("RGB")) for r in raws]
+
+
+def oracle_logits(key: str, set_name: str, raws) -> np.ndarray:
+    """fp32 oracle logits of member `key` on the JPEG byte strings `raws` (cached per (member, set_name))."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import zoo
+    ck = (key, set_name, len(raws))
+    if ck not in _CACHE:
+        spec = zoo.MEMBERS[key]
+        pix = decode_pixels(raws)
+        x = torch.stack([R.decode_resize_normalize(p, spec.input_hw, spec.input_hw) for p in pix])
+        ref = importlib.import_module(f"oracle.{spec.oracle}")
+        params = zoo.build_params(key)
+        out = []
+        with torch.no_grad():
+            for i in range(0, len(raws), 16):
+                out.append(ref.predict_logits(key, params, x[i:i + 16]).numpy()[:, 0])
+        _CACHE[ck] = np.concatenate(out)
+    return _CACHE[ck]
+
+
+_MODELS = {}
+
+
+def gpu_member(key: str):
+    """(spec, model) built once per session (construction includes the bias-calibration pass)"""
+    from vipcup_amd import zoo
+    if key not in _MODELS:
+        _MODELS[key] = zoo.build_member(key)
+    return _MODELS[key]
+
+
+def logit(p):
+    p = np.clip(p, 1e-7, 1 - 1e-7)
+    return np.log(p / (1 - p))
+
+
+def sigmoid(z):
+    return 1.0 / (1.0 + np.exp(-z))
+
+
+def real_photo_tiles():
+    """>= 12 JPEG byte strings that are NOT from tools/make_synth: 200x200 tiles of the three photographs the reference embeds
+    (tests/golden/ref_*.jpg, 512x512), re-encoded at quality 75 / 90, 4:2:0 / 4:4:4."""
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    raws = []
+    k = 0
+    for name in ("ref_cat.jpg", "ref_dog.jpg", "ref_dog_cat.jpg"):
+        img = Image.open(os.path.join(here, name)).convert("RGB")
+        for (x0, y0) in ((20, 30), (290, 40), (60, 300), (300, 290), (150, 160)):
+            buf = io.BytesIO()
+            img.crop((x0, y0, x0 + 200, y0 + 200)).save(buf, format="JPEG", quality=(75, 90)[k % 2], subsampling=(2, 0)[(k // 2) % 2])
+            raws.append(buf.getvalue())
+            k += 1
+    return raws

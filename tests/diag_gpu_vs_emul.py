@@ -1,0 +1,60 @@
+"""Diagnostic (not a pytest file; GPU box): per member, the calibrated logit from (a) the fp32 oracle, (b) the CPU emulation of the
+product graph (fp16 weights as shipped, every operator output rounded to fp16) and (c) the HIP path, on the same images.
+gpu - emul isolates what the kernels add beyond storage rounding.   python tests/diag_gpu_vs_emul.py [n] [member ...]"""
+import importlib, io, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from PIL import Image
+import vipcup_amd  # noqa
+from vipcup_amd import zoo, gcvit, resnet_rs, tfimm_models as tm, kecam_models as km, ops, pipeline
+from oracle import ops_ref as R
+from tests import emul_ops
+from tools.make_synth import synth_jpeg
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+members = sys.argv[2:] or zoo.ENSEMBLE
+CTORS = {"gcvit_tiny": lambda p: gcvit.GCViTTiny(p, device="cpu"),
+         "efficientnet_v1b4": lambda p: km.EfficientNet(p, "EfficientNetV1B4", device="cpu"),
+         "efficientnet_v2t": lambda p: km.EfficientNet(p, "EfficientNetV2T", device="cpu"),
+         "resnest50": lambda p: km.ResNest(p, device="cpu"),
+         "eca_nfnet_l0": lambda p: km.NormFreeNet(p, device="cpu"),
+         "resnet_rs50": lambda p: resnet_rs.ResNetRS50(p, device="cpu"),
+         "convnext_tiny_in22k": lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_tiny_in22k"], device="cpu"),
+         "vit_small_patch16_224": lambda p: tm.ViT(p, tm.VIT_CONFIGS["vit_small_patch16_224"], device="cpu")}
+raws = [synth_jpeg(100 + i) for i in range(n)]
+pix = [np.asarray(Image.open(io.BytesIO(r)).convert("RGB")) for r in raws]
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+out = {}
+
+
+def st(d):
+    return f"rms {np.sqrt((d**2).mean()):.2e} mean {d.mean():+.2e} max {np.abs(d).max():.2e}"
+
+
+for key in members:
+    spec = zoo.MEMBERS[key]
+    x = torch.stack([R.decode_resize_normalize(p, spec.input_hw, spec.input_hw) for p in pix])
+    params = zoo.build_params(key)
+    ref = importlib.import_module(f"oracle.{spec.oracle}")
+    with torch.no_grad():
+        z = ref.predict_logits(key, params, x)[:, 0].numpy()
+        # HIP path: same decoded pixels through the product pipeline
+        _, model = zoo.build_member(key)
+        xg = pipeline.decode_jpegs(raws).resized(spec.input_hw, spec.input_hw)
+        zg = model.logits(xg)[:, 0].float().cpu().numpy()
+        # emulation: product graph on the CPU, calibration as the product does it (same calibration batch)
+        x8 = emul_ops.to_device_nhwc8(xg[..., :3].float().cpu())
+        cal = pipeline.calibration_batch().resized(spec.input_hw, spec.input_hw)[..., :3].float().cpu()
+        ops.KEEP_ROUNDING_ERROR = True
+        emul_ops.BIAS_CORRECT = False
+        with emul_ops.patched(round_act=True):
+            m = CTORS[key](params)
+            ops._CALIB = True
+            m.logits(emul_ops.to_device_nhwc8(cal))
+            ops._CALIB = False
+            ze = m.logits(x8)[:, 0].float().numpy()
+        ops.KEEP_ROUNDING_ERROR = False
+    print(f"{key:22s} gpu-oracle {st(zg - z)} | emul-oracle {st(ze - z)} | gpu-emul {st(zg - ze)}", flush=True)
+    out[key] = {"oracle": z.tolist(), "gpu": zg.tolist(), "emul": ze.tolist()}
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open("gpurun_out/diag_gpu_vs_emul.json", "w"))

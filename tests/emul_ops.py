@@ -10,6 +10,7 @@ import torch
 from oracle import ops_ref as R
 
 ROUND_ACT = False
+EXACT_W = False          # diagnostic: use the fp32 weights (stored fp16 + kept rounding error)
 BIAS_CORRECT = False     # add (W32 - W16) . E[x] to every conv/dense output (what calibrated bias correction does)
 ACTN = {0: None, 1: "relu", 2: "silu", 3: "gelu", 4: "sigmoid", None: None}
 
@@ -28,6 +29,8 @@ def _an(a):
 def _w(cw):
     k = cw.kh * cw.kw * cw.cin_g
     w = cw.w.float() if getattr(cw, "w_lo", None) is None else cw.w.float() + cw.w_lo.float()     # two-term weights
+    if EXACT_W and cw.err is not None:
+        w = w + cw.err
     return w[:, :k].reshape(cw.cout, cw.kh, cw.kw, cw.cin_g).permute(1, 2, 3, 0)
 
 
@@ -36,8 +39,9 @@ def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=
     xx = x[..., cin_off:cin_off + cw.cin]
     if gate is not None:
         xx = _r(xx * _gate(gate)[:, None, None, :], "gate_mul")
+    _calib(cw, xx)
     y = R.conv2d(xx, _w(cw), cw.bias, stride, pad, cw.groups)
-    if BIAS_CORRECT and cw.err is not None:
+    if BIAS_CORRECT and not EXACT_W and cw.err is not None:
         mu = xx.reshape(-1, xx.shape[-1]).mean(0)                                  # [Cin]
         k = cw.kh * cw.kw * cw.cin_g
         e = cw.err[:, :k].reshape(cw.cout, cw.kh * cw.kw, cw.cin_g)
@@ -54,14 +58,22 @@ def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=
     return y
 
 
+def _calib(cw, xx):
+    """inside the product's ops.calibration(): fold (W32 - W16) . E[x] into the bias, exactly as ops.conv2d / ops.dense do"""
+    from vipcup_amd import ops
+    if ops._CALIB and cw.err is not None:
+        ops._bias_correct(cw, xx)
+
+
 def dense(x, cw, act=None, act_post=None, residual=None, tag="dense"):
+    _calib(cw, x)
     y = x @ _w(cw)[0, 0] + (cw.bias if cw.bias is not None else 0)
-    if BIAS_CORRECT and cw.err is not None:
+    if BIAS_CORRECT and not EXACT_W and cw.err is not None:
         y = y + cw.err[:, :x.shape[-1]] @ x.reshape(-1, x.shape[-1]).mean(0)
     y = R.act(y, _an(act))
     if residual is not None:
         y = y + residual
-    return _r(R.act(y, _an(act_post)), tag)
+    return _r(R.act(y, _an(act_post)), "stream" if (residual is not None and tag == "dense") else tag)
 
 
 def mlp(x, fc1, fc2, act="gelu", residual=None, ln=None):
@@ -138,7 +150,7 @@ def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
         y = y * scale.reshape(scale.shape[0], *([1] * (x.dim() - 2)), scale.shape[-1])
     if residual is not None:
         y = y + residual
-    return _r(R.act(y, _an(act)), "saa")
+    return _r(R.act(y, _an(act)), "saa" if residual is None else "saa_res")
 
 
 def mul(a, b, c, a_off=0, b_off=0):

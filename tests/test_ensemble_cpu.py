@@ -65,46 +65,81 @@ def test_tta_flags_follow_apply_augment_and_do_not_depend_on_sharding():
     assert np.allclose(ref, small, atol=1e-6)
     lo, hi = ensemble.shard_bounds(n, 1, 2)
     part = ensemble.score_files(lambda a, b: jpegs_for(a, b), n, [(None, None)] * 2, batch_size=16, rank=1, world=2,
-                                dist=None, scorer=scorer, tta=4, tta_seed=9)
-    assert np.allclose(part, ref[:, lo:hi], atol=1e-6)
+                                dist=None, scorer=scorer, tta=4, tta_seed=9)      # no exchange: only rank 1's shard is filled in
+    assert np.allclose(part[:, lo:hi], ref[:, lo:hi], atol=1e-6) and not part[:, :lo].any()
 
 
-def _worker(rank, world, port, n, q):
+def _id_scorer(raws, members, flags=None):
+    """stand-in for the GPU path: score = f(member id, image id); members = [(member id, None)]"""
+    ids = torch.tensor([r[0] for r in raws], dtype=torch.float32)
+    return torch.stack([(ids * (mid + 1) % 97) / 97.0 for mid, _ in members], 0)
+
+
+def _worker(rank, world, port, n, mode, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ensemble
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    real = dist.all_gather_into_tensor
+
+    def counting(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    dist.all_gather_into_tensor = counting
 
     def jpegs_for(lo, hi):
         return [bytes([i % 251]) for i in range(lo, hi)]
 
-    def scorer(raws, members):  # stand-in for the GPU path: score = f(member, image id)
-        ids = torch.tensor([r[0] for r in raws], dtype=torch.float32)
-        return torch.stack([(ids * (m + 1) % 97) / 97.0 for m in range(len(members))], 0)
-
-    out = ensemble.score_files(jpegs_for, n, [(None, None)] * 3, batch_size=16, rank=rank, world=world, dist=dist,
-                               scorer=scorer)
-    q.put((rank, out))
+    out = ensemble.score_files(jpegs_for, n, [(m, None) for m in range(5)], batch_size=16, rank=rank, world=world, dist=dist,
+                               scorer=_id_scorer, shard=mode, costs=[16.8, 9.3, 8.0, 6.5, 4.9])
+    q.put((rank, out, len(calls)))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [37, 2])
-def test_two_rank_gloo_exchange(n):
+@pytest.mark.parametrize("world,n,mode", [(2, 37, "images"), (2, 2, "images"), (2, 37, "members"), (2, 37, "hybrid"),
+                                          (4, 37, "images"), (4, 37, "members"), (4, 37, "hybrid"), (4, 3, "hybrid")])
+def test_multi_rank_gloo_exchange(world, n, mode):
+    """world_size 2 and 4 over gloo, every ShardPlan mode: scores identical to the single-process result, ONE all-gather."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500) + n
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + world * 31 + n + len(mode) * 3) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=60) for _ in procs)
+    res = {}
+    for _ in procs:
+        r, out, ncalls = q.get(timeout=120)
+        res[r] = out
+        assert ncalls == 1, f"rank {r}: {ncalls} all-gathers on the data path"
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     ids = np.arange(n, dtype=np.float32) % 251
-    want = np.stack([(ids * (m + 1) % 97) / 97.0 for m in range(3)], 0)
-    for r in (0, 1):
-        assert res[r].shape == (3, n)
-        assert np.allclose(res[r], want)
+    want = np.stack([(ids * (m + 1) % 97) / 97.0 for m in range(5)], 0)
+    for r in range(world):
+        assert res[r].shape == (5, n)
+        assert np.allclose(res[r], want), (mode, r)
+
+
+def test_shard_plans_partition_the_work():
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ensemble
+    costs = [16.8, 9.3, 8.0, 6.5, 6.2, 5.6, 4.9, 7.0]          # ms per 256 images, the eight config-5 members
+    for world in (1, 2, 4, 8):
+        for mode in ensemble.SHARD_MODES:
+            plan = ensemble.ShardPlan(mode, len(costs), world, costs)
+            owned = sorted((m, s) for u in plan.units for s, ms in u.items() for m in ms)
+            assert owned == sorted((m, s) for m in range(len(costs)) for s in range(world)), (mode, world)
+            assert ensemble.ShardPlan(mode, len(costs), world, costs).units == plan.units      # deterministic
+    members8 = ensemble.ShardPlan("members", 8, 8, costs)
+    assert all(list(u.values())[0] == [r] and sorted(u) == list(range(8)) for r, u in enumerate(members8.units))
+    # LPT: the critical path of hybrid is within one unit of the mean load; member-parallel is capped by the slowest member
+    hyb = ensemble.ShardPlan("hybrid", 8, 8, costs)
+    mean = sum(costs)
+    assert max(hyb.load) <= mean + min(costs) and max(hyb.load) < 8 * max(costs)
+    with pytest.raises(ValueError):
+        ensemble.ShardPlan("rows", 2, 2)

@@ -1,0 +1,81 @@
+"""GPU parity beyond the 16-image CLI test: images that are NOT from the synthetic family, every shipped member
+inside a 256-image batch (the kernels bench.py times), and the BASELINE config-4 / config-5 member lists."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests import _parity as P  # noqa: E402
+from tools.make_synth import synth_jpeg  # noqa: E402
+
+
+def _gpu_logits(key, raws, batch=None):
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import pipeline
+    spec, model = P.gpu_member(key)
+    x = pipeline.decode_jpegs(raws).resized(spec.input_hw, spec.input_hw)
+    return model.logits(x)[:, 0].float().cpu().numpy()
+
+
+def _members():
+    from vipcup_amd import zoo
+    return list(zoo.ENSEMBLE)
+
+
+def test_real_photo_tiles_match_oracle(report):
+    """Off the calibration distribution: the bias calibration (ops.calibration) is fitted on a seeded batch of the synthetic family;
+    these 15 tiles are photographs.  Same bounds as on the synthetic set."""
+    raws = P.real_photo_tiles()
+    assert len(raws) >= 12
+    probs_g, probs_o, over = [], [], {}
+    for key in _members():
+        z = P.oracle_logits(key, "photo_tiles", raws)
+        zg = _gpu_logits(key, raws)
+        dz = np.abs(zg - z)
+        report(f"[photo] {key:22s} max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e} z range [{z.min():+.2f},{z.max():+.2f}]"
+               f"{'' if dz.max() <= P.TOL_NORTH_STAR else '   ABOVE north-star 1e-3'}")
+        if dz.max() > P.MEMBER_CEILING[key]:
+            over[key] = float(dz.max())
+        probs_g.append(P.sigmoid(zg))
+        probs_o.append(P.sigmoid(z))
+    dm = np.abs(np.mean(probs_g, 0) - np.mean(probs_o, 0)).max()
+    report(f"[photo] ensemble mean max|dp|={dm:.3e}")
+    assert not over, f"members above their ceiling on photo tiles: {over}"
+    assert dm <= P.TOL_ENSEMBLE_PROB
+
+
+@pytest.mark.parametrize("key", ["convnext_tiny_in22k", "resnest50", "gcvit_tiny", "efficientnet_v2t", "efficientnet_v1b4",
+                                 "eca_nfnet_l0", "resnet_rs50"])
+def test_member_inside_batch_256(key, report):
+    """The dispatcher keys on the row count M = B x pixels, so at B = 256 the deep stages run on other kernels than in the
+    8-image model tests (and the fused MLP / streaming GEMMs switch on).  Images 0-7 of a 256-image batch vs the oracle, and vs
+    the same 8 images scored alone."""
+    raws = [synth_jpeg(1000 + i) for i in range(256)]
+    z = P.oracle_logits(key, "b256_first8", raws[:8])
+    z256 = _gpu_logits(key, raws)
+    z8 = _gpu_logits(key, raws[:8])
+    assert np.isfinite(z256).all()
+    d_or = np.abs(z256[:8] - z).max()
+    d_self = np.abs(z256[:8] - z8).max()
+    report(f"[b256] {key:22s} images 0-7 in a 256-batch: max|dz| vs oracle {d_or:.3e}, vs the B=8 run {d_self:.3e}; "
+           f"logit spread over the batch {z256.std():.2f}")
+    assert d_or <= P.MEMBER_CEILING[key]
+    assert d_self <= 2 * P.MEMBER_CEILING[key]      # two independent fp16 realisations of the same graph
+
+
+@pytest.mark.parametrize("name", ["ensemble4", "ensemble8"])
+def test_workload_scores_match_oracle(name, report):
+    """BASELINE configs 4 and 5 through the bench's own workload object: JPEG bytes in host RAM -> scores."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import workloads
+    n = 16
+    raws = [synth_jpeg(300 + i) for i in range(n)]
+    wl = workloads.build(name, batch=n, jpegs=raws)
+    got = wl.step().float().cpu().numpy().reshape(-1)
+    got2 = wl.step().float().cpu().numpy().reshape(-1)        # the second step runs on the member streams
+    probs = [P.sigmoid(P.oracle_logits(k, "wl16", raws)) for k in wl.members]
+    want = np.mean(probs, 0)
+    d, d2 = np.abs(got - want).max(), np.abs(got2 - want).max()
+    report(f"[{name}] {len(wl.members)} members, 16 JPEGs -> ensemble mean: max|dp| vs oracle {d:.3e} (step 2: {d2:.3e})")
+    assert d <= P.TOL_ENSEMBLE_PROB and d2 <= P.TOL_ENSEMBLE_PROB

@@ -1092,6 +1092,18 @@ int launch(const ConvArgs& a0, int groups, hipStream_t s) {
 
 }  // namespace
 
+// vip_conv2d_kernel_name(): the selection below runs with g_dry set, records the kernel it would launch and returns
+static thread_local bool g_dry = false;
+static thread_local const char* g_pick = "";
+#define VIP_PICK(name, call)          \
+    do {                              \
+        if (g_dry) {                  \
+            g_pick = (name);          \
+            return VIP_OK;            \
+        }                             \
+        return (call);                \
+    } while (0)
+
 static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void* w, const float* bias, const void* residual, void* y,
                        const vip_conv_desc* d, void* stream, const void* w_lo = nullptr) {
     VIP_REQUIRE(x && w && y && d, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_f16: null pointer");
@@ -1155,28 +1167,29 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
         if (w_lo) {     // hi + lo weights: the streaming kernel is the one that carries them (any M)
             VIP_REQUIRE(mode >= 0 && short_k && !gate && !y_lo_off, VIP_ERR_UNSUPPORTED,
                         "vip_conv2d_hilo_nhwc_f16: 1x1 stride-1 ungrouped, K <= 256, (activation) or (residual [+ReLU]) epilogue");
-            return launch_pw_k<4>(a, mode, s);
+            VIP_PICK("pw_gemm_kernel", launch_pw_k<4>(a, mode, s));
         }
         if (M <= 256 && !residual && !gate && d->act_post == VIP_ACT_NONE && d->ldy % 4 == 0 && d->cout_off % 4 == 0 &&
             a.x_span_bytes < 0xFFFF0000L - 2L * a.K && 2L * cout_g * d->ldw < 0xFFFF0000L - 2L * a.K) {
+            if (g_dry) { g_pick = "rows_gemm_kernel"; return VIP_OK; }
             hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)((cout_g + 15) / 16), (unsigned)((M + 63) / 64)), dim3(256), 0, s, a);
             return vip_launch_status("vip_conv2d_nhwc_f16(rows)");
         }
         VIP_REQUIRE(!y_lo_off, VIP_ERR_UNSUPPORTED, "vip_gemm_split_f16: at most 256 rows, N %% 4 == 0");
-        if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) return launch_pw_k<4>(a, mode, s);
+        if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) VIP_PICK("pw_gemm_kernel", launch_pw_k<4>(a, mode, s));
         if (mode >= 0 && (pw_mode & 2) && a.x_span_bytes < 0xFFFFFFF0L) {
             // (a 64 x 256 wave tile at one wave per SIMD - NG = 4 - measured 15-40 % slower than NG = 2 at two)
             static const int xl_min_k = getenv("VIP_PWK_XLK") ? atoi(getenv("VIP_PWK_XLK")) : 768;
             // (gated convolutions: only the direct kernel carries the gate pipeline - their deep-K cases are small launches)
             if ((a.K < xl_min_k || gate) && a.x_span_bytes < 0xFFFF0000L - 2L * a.K)
-                return cout_g <= 64 ? launch_pwk_direct<1>(a, mode, s) : launch_pwk_direct<2>(a, mode, s);
+                VIP_PICK("pwk_direct_kernel", cout_g <= 64 ? launch_pwk_direct<1>(a, mode, s) : launch_pwk_direct<2>(a, mode, s));
             VIP_REQUIRE(!gate, VIP_ERR_UNSUPPORTED, "vip_conv2d_gated_nhwc_f16: input tensor too large (4 GB - 2K)");
-            if (cout_g <= 64) return launch_pwk<1, 1>(a, mode, s);
+            if (cout_g <= 64) VIP_PICK("pwk_gemm_kernel", (launch_pwk<1, 1>(a, mode, s)));
             // 256 x 256 block tiles (8 waves): 5 % on deep-K layers whose N is a multiple of 256; slower whenever the last
             // 256-channel tile is half empty (N = 384: 258 -> 346 us) or K is short
             static const int wn2_min_k = getenv("VIP_PWK_WN2K") ? atoi(getenv("VIP_PWK_WN2K")) : 1024;
-            if (cout_g % 256 == 0 && a.K >= wn2_min_k && (long)((M + 255) / 256) * (cout_g / 256) >= 256) return launch_pwk<2, 2>(a, mode, s);
-            return launch_pwk<2, 1>(a, mode, s);
+            if (cout_g % 256 == 0 && a.K >= wn2_min_k && (long)((M + 255) / 256) * (cout_g / 256) >= 256) VIP_PICK("pwk_gemm_kernel", (launch_pwk<2, 2>(a, mode, s)));
+            VIP_PICK("pwk_gemm_kernel", (launch_pwk<2, 1>(a, mode, s)));
         }
     }
     {   // k x k convolutions on the pointwise kernel with im2col staging (64 px x 128 ch wave tiles, half the LDS fragment
@@ -1191,14 +1204,14 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
         static const int im2col_all = getenv("VIP_PWK_CONV") ? atoi(getenv("VIP_PWK_CONV")) : 0;
         if ((cin_g <= 16 || im2col_all > 0 || (im2col_all == 0 && M >= 32768)) && mode >= 0 && !gate && a.x_span_bytes < 0xFFFFFFF0L && d->H < 30000 &&
             d->W < 30000 && d->pt < 16 && d->pl < 16)
-            return cout_g <= 64 ? launch_pwk_conv<1>(a, mode, d->groups, s) : launch_pwk_conv<2>(a, mode, d->groups, s);
+            VIP_PICK("pwk_gemm_kernel(im2col)", cout_g <= 64 ? launch_pwk_conv<1>(a, mode, d->groups, s) : launch_pwk_conv<2>(a, mode, d->groups, s));
     }
     VIP_REQUIRE(!w_lo, VIP_ERR_UNSUPPORTED, "vip_conv2d_hilo_nhwc_f16: only 1x1 stride-1 ungrouped convolutions with K <= 256");
     VIP_REQUIRE(!gate, VIP_ERR_UNSUPPORTED,
                 "vip_conv2d_gated_nhwc_f16: only 1x1 stride-1 ungrouped convolutions with (activation) or (residual [+ReLU]) "
                 "epilogues take a gate; apply vip_scale_add_act_f16 first");
-    if (cout_g <= 64) return short_k ? launch<64, 64>(a, d->groups, s) : launch<128, 64>(a, d->groups, s);
-    return short_k ? launch<64, 128>(a, d->groups, s) : launch<128, 128>(a, d->groups, s);
+    if (cout_g <= 64) VIP_PICK("conv_igemm_kernel", short_k ? (launch<64, 64>(a, d->groups, s)) : (launch<128, 64>(a, d->groups, s)));
+    VIP_PICK("conv_igemm_kernel", short_k ? (launch<64, 128>(a, d->groups, s)) : (launch<128, 128>(a, d->groups, s)));
 }
 
 extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, const void* residual, void* y,
@@ -1218,6 +1231,20 @@ extern "C" int vip_conv2d_hilo_nhwc_f16(const void* x, const void* w_hi, const v
                                         const void* residual, void* y, const vip_conv_desc* d, void* stream) {
     VIP_REQUIRE(w_lo, VIP_ERR_BAD_ARG, "vip_conv2d_hilo_nhwc_f16: null w_lo");
     return conv2d_impl(x, nullptr, 0, w_hi, bias, residual, y, d, stream, w_lo);
+}
+
+extern "C" int vip_conv2d_kernel_name(const vip_conv_desc* d, int has_residual, int has_gate, int has_w_lo, char* name,
+                                      size_t cap) {
+    VIP_REQUIRE(d && name && cap > 0, VIP_ERR_BAD_ARG, "vip_conv2d_kernel_name: null pointer");
+    static const char dummy[16] = {0};     // non-null stand-ins: nothing is dereferenced or launched in a dry run
+    g_dry = true;
+    g_pick = "";
+    const int st = conv2d_impl(dummy, has_gate ? dummy : nullptr, 0, dummy, nullptr, has_residual ? dummy : nullptr,
+                               const_cast<char*>(dummy), d, nullptr, has_w_lo ? dummy : nullptr);
+    g_dry = false;
+    if (st != VIP_OK) return st;
+    snprintf(name, cap, "%s", g_pick);
+    return VIP_OK;
 }
 
 extern "C" int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const void* residual,

@@ -4,10 +4,12 @@ Reference flow per model: rebuild the dataset (re-decoding every JPEG), ``model.
 mean over TTA (:111), multi-class -> binary ``1 - p[:,0]`` (:113-114), mean over folds (:121); then across
 models: concat, ``groupby(filename).mean()`` (:142-143), ``(mean > thr) * 1.0`` (:144), CSV (:145).
 
-Here: each batch of files is decoded ONCE, every member consumes the resident pixels at its own resolution,
-and with N > 1 processes the IMAGES are sharded across ranks (every rank holds all members — 175 M parameters
-are nothing next to 288 GB) with one all-gather of the per-image scores at the end (the only exchange step;
-SURVEY.md §8e).
+Here: each batch of files is decoded ONCE, every member consumes the resident pixels at its own resolution.
+With N > 1 processes the work is a grid of (member, image-shard) units dealt to the ranks by a ``ShardPlan``:
+``images`` (every rank holds all members and scores its own image shard - what MirroredStrategy does, utils/device.py:7),
+``members`` (rank r owns members m = r mod world and sees every image - the one-model-per-GPU split of BASELINE.json) or
+``hybrid`` (longest-processing-time-first packing of the units by measured ms/image).  In every mode the only exchange step
+is ONE all-gather of the ranks' score payloads at the end.
 """
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -36,6 +38,89 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+SHARD_MODES = ("images", "members", "hybrid")
+
+
+class ShardPlan:
+    """Who scores what: ``units[r]`` = {image-shard s: [member index, ...]} for rank r; image-shard s = ``shard_bounds(n, s, world)``.
+    Every (member, shard) pair is owned by exactly one rank.  The plan is a pure function of (mode, n_members, world, costs), so
+    every rank derives the same one without talking to the others."""
+
+    def __init__(self, mode: str, n_members: int, world: int, costs: Optional[Sequence[float]] = None):
+        if mode not in SHARD_MODES:
+            raise ValueError(f"shard mode {mode!r}: expected one of {SHARD_MODES}")
+        self.mode, self.n_members, self.world = mode, n_members, world
+        units: List[Dict[int, List[int]]] = [dict() for _ in range(world)]
+        if mode == "images" or world == 1:
+            for r in range(world):
+                units[r][r] = list(range(n_members))
+        elif mode == "members":
+            for r in range(world):
+                mine = [m for m in range(n_members) if m % world == r]
+                if mine:
+                    for s in range(world):
+                        units[r][s] = list(mine)
+        else:       # hybrid: LPT over the n_members x world units; a unit costs the member's ms/image (shards are equal-sized)
+            c = [1.0] * n_members if costs is None else [float(v) for v in costs]
+            assert len(c) == n_members
+            order = sorted(((c[m], m, s) for m in range(n_members) for s in range(world)), key=lambda t: (-t[0], t[1], t[2]))
+            load = [0.0] * world
+            for cost, m, s in order:
+                # least-loaded rank; ties go to the rank that already decodes shard s (no extra decode), then to the lowest rank
+                r = min(range(world), key=lambda k: (round(load[k], 9), 0 if s in units[k] else 1, k))
+                units[r].setdefault(s, []).append(m)
+                load[r] += cost
+            for r in range(world):
+                for s in units[r]:
+                    units[r][s].sort()
+            self.load = load
+        self.units = units
+
+    def payload_len(self, rank: int, n_images: int) -> int:
+        return sum(len(ms) * (shard_bounds(n_images, s, self.world)[1] - shard_bounds(n_images, s, self.world)[0])
+                   for s, ms in self.units[rank].items())
+
+    def describe(self) -> str:
+        return "; ".join(f"rank {r}: " + ", ".join(f"shard {s} x members {ms}" for s, ms in sorted(u.items()))
+                         for r, u in enumerate(self.units))
+
+
+def gather_plan_scores(plan: ShardPlan, rank: int, n_images: int, local: Dict[Tuple[int, int], torch.Tensor], dist=None,
+                       device=None) -> torch.Tensor:
+    """The exchange step.  ``local[(s, m)]`` = scores of member m on image-shard s (1-D, this rank's units).  Each rank's
+    payload (its units back to back, in (shard, member) order, padded to the longest payload) goes through ONE
+    ``all_gather_into_tensor`` (RCCL over xGMI on GPUs, gloo in the CPU tests); returns ``[n_members, n_images]`` on every rank."""
+    world = plan.world
+    lens = [plan.payload_len(r, n_images) for r in range(world)]
+    width = max(max(lens), 1)
+    if device is None:
+        device = next(iter(local.values())).device if local else torch.device("cpu")
+    mine = torch.zeros((width,), dtype=torch.float32, device=device)
+    off = 0
+    for s in sorted(plan.units[rank]):
+        for m in plan.units[rank][s]:
+            v = local[(s, m)].reshape(-1).to(torch.float32)
+            mine[off:off + v.numel()] = v
+            off += v.numel()
+    assert off == lens[rank], (off, lens[rank])
+    if dist is not None and world > 1:
+        allp = torch.empty((world * width,), dtype=torch.float32, device=device)     # flat: every backend accepts this form
+        dist.all_gather_into_tensor(allp, mine)
+        allp = allp.view(world, width)
+    else:
+        allp = mine.view(1, width)
+    full = torch.zeros((plan.n_members, n_images), dtype=torch.float32, device=device)
+    gathered = dist is not None and world > 1
+    for r in (range(world) if gathered else [rank]):     # without an exchange only this rank's units are known
+        off = 0
+        for s in sorted(plan.units[r]):
+            lo, hi = shard_bounds(n_images, s, world)
+            for m in plan.units[r][s]:
+                full[m, lo:hi] = allp[r if gathered else 0, off:off + (hi - lo)]
+                off += hi - lo
+    return full
+
+
 def to_binary(pred: np.ndarray) -> np.ndarray:
     """main.py:113-114: a multi-class head reports P(real) in column 0 -> P(synthetic) = 1 - p[:,0]"""
     pred = np.asarray(pred, dtype=np.float32)
@@ -60,22 +145,6 @@ def aggregate(filenames: Sequence[str], per_model: np.ndarray, thr: float = THR)
     return uniq.tolist(), score, (score > thr).astype(np.float32)
 
 
-def all_gather_scores(local: torch.Tensor, counts: List[int], dist=None) -> torch.Tensor:
-    """The exchange step: every rank contributes ``[M, n_local]`` scores; returns ``[M, sum(counts)]`` in rank
-    order on every rank.  Shards are padded to the largest count so ONE all_gather (RCCL over xGMI on GPUs,
-    gloo in the CPU tests) moves everything."""
-    if dist is None or len(counts) == 1:
-        return local
-    M = local.shape[0]
-    width = max(counts)
-    pad = torch.zeros((M, width), dtype=local.dtype, device=local.device)
-    pad[:, :local.shape[1]] = local
-    out = torch.empty((len(counts) * M, width), dtype=local.dtype, device=local.device)  # concatenated along dim 0
-    dist.all_gather_into_tensor(out, pad)
-    out = out.view(len(counts), M, width)
-    return torch.cat([out[r, :, :c] for r, c in enumerate(counts)], dim=1)
-
-
 def tta_flags(n_images: int, tta: int, seed: int = 0) -> np.ndarray:
     """The random draws of ``apply_augment`` (dataset/augment.py:153-182 with RandomFlip :115-120, RandomGray
     :142-146) for every (pass, image): bool ``[tta, n_images, 3]`` = (hflip, vflip, gray).  With probability 0.2 an
@@ -94,23 +163,29 @@ def tta_flags(n_images: int, tta: int, seed: int = 0) -> np.ndarray:
 
 def score_files(jpegs_for: Callable[[int, int], List[bytes]], n_images: int, members: List[Tuple[object, object]],
                 batch_size: int = REF_BATCH, rank: int = 0, world: int = 1, dist=None,
-                scorer: Optional[Callable] = None, tta: int = 1, tta_seed: int = 0) -> np.ndarray:
+                scorer: Optional[Callable] = None, tta: int = 1, tta_seed: int = 0,
+                shard: str = "images", costs: Optional[Sequence[float]] = None) -> np.ndarray:
     """Score images [0, n_images) with every member; returns ``[M, n_images]`` fp32 probabilities on every rank.
 
     ``jpegs_for(lo, hi)`` returns the JPEG byte strings of images lo..hi-1 (read lazily, per batch).
     ``members`` = [(spec, model)] with ``spec.input_hw`` and ``model.predict(x) -> [n, C]``.
     ``tta`` > 1: every image is scored ``tta`` times under ``apply_augment`` draws and the predictions are averaged
     (main.py:92,109-111, ``CFG.agg = 'mean'``); the JPEGs are still decoded once.
+    ``shard`` / ``costs``: the ShardPlan mode and, for ``hybrid``, the per-member cost (ms/image; identical on every rank).
+    A rank only calls ``model.predict`` of the members its plan names, so under ``members`` / ``hybrid`` the others need not
+    be resident (``members[i][1]`` may be None there).
     ``scorer(raws, members[, flags]) -> [M, n]`` replaces the GPU path in the CPU (gloo) tests."""
-    lo, hi = shard_bounds(n_images, rank, world)
-    counts = [shard_bounds(n_images, r, world)[1] - shard_bounds(n_images, r, world)[0] for r in range(world)]
+    plan = ShardPlan(shard, len(members), world, costs)
     flags_all = tta_flags(n_images, tta, tta_seed) if tta > 1 else None
-    chunks = []
-    starts = list(range(lo, hi, batch_size))
+    work = []                                   # (shard, member indices, b0, b1)
+    for s in sorted(plan.units[rank]):
+        lo, hi = shard_bounds(n_images, s, world)
+        for b0 in range(lo, hi, batch_size):
+            work.append((s, plan.units[rank][s], b0, min(b0 + batch_size, hi)))
 
-    def host_stage(b0):
+    def host_stage(item):
         """file read + Huffman decode of one batch (C++ threads, the GIL is released inside the ctypes call)"""
-        raws = jpegs_for(b0, min(b0 + batch_size, hi))
+        raws = jpegs_for(item[2], item[3])
         if scorer is not None:
             return raws
         from . import pipeline
@@ -119,24 +194,29 @@ def score_files(jpegs_for: Callable[[int, int], List[bytes]], n_images: int, mem
     # one batch of read-ahead: the host stage of batch i+1 runs while the GPU scores batch i (the reference gets the
     # same overlap from tf.data's prefetch, dataset/dataset.py:101)
     from concurrent.futures import ThreadPoolExecutor
+    chunks: Dict[Tuple[int, int], List[torch.Tensor]] = {}
     with ThreadPoolExecutor(max_workers=1) as pool:
-        nxt = pool.submit(host_stage, starts[0]) if starts else None
-        for i, b0 in enumerate(starts):
-            b1 = min(b0 + batch_size, hi)
+        nxt = pool.submit(host_stage, work[0]) if work else None
+        for i, (s, midx, b0, b1) in enumerate(work):
             staged = nxt.result()
-            nxt = pool.submit(host_stage, starts[i + 1]) if i + 1 < len(starts) else None
+            nxt = pool.submit(host_stage, work[i + 1]) if i + 1 < len(work) else None
+            sub = [members[m] for m in midx]
             fl = None if flags_all is None else flags_all[:, b0:b1]
             if scorer is not None:
-                chunks.append(scorer(staged, members) if fl is None else scorer(staged, members, fl))
+                rows = scorer(staged, sub) if fl is None else scorer(staged, sub, fl)
             else:
-                chunks.append(_score_batch(staged, members, fl))
-    M = len(members)
-    if chunks:
-        local = torch.cat(chunks, dim=1)
-    else:
-        dev = "cuda" if (scorer is None and torch.cuda.is_available()) else "cpu"
-        local = torch.zeros((M, 0), dtype=torch.float32, device=dev)
-    full = all_gather_scores(local, counts, dist)
+                rows = _score_batch(staged, sub, fl)
+            for j, m in enumerate(midx):
+                chunks.setdefault((s, m), []).append(rows[j])
+    local = {k: torch.cat(v) for k, v in chunks.items()}
+    dev = None
+    if not local:
+        dev = torch.device("cuda" if (scorer is None and torch.cuda.is_available()) else "cpu")
+    for s in plan.units[rank]:                  # empty shards (more ranks than images)
+        for m in plan.units[rank][s]:
+            if (s, m) not in local:
+                local[(s, m)] = torch.zeros((0,), dtype=torch.float32, device=dev or next(iter(local.values())).device)
+    full = gather_plan_scores(plan, rank, n_images, local, dist, dev)
     return full.detach().float().cpu().numpy()
 
 
@@ -152,7 +232,8 @@ class MemberStreams:
     def __init__(self, n_streams: int):
         self.n = max(1, int(n_streams))
         self.streams = [torch.cuda.Stream() for _ in range(self.n)] if self.n > 1 else []
-        self.assign: Optional[List[List[int]]] = None
+        self._assign: Dict[Tuple[str, ...], List[List[int]]] = {}    # per member list (a ShardPlan may hand over sub-lists)
+        self.cost_ms: Dict[str, float] = {}                              # last one-off timing per member (ms per batch)
 
     def _calibrate(self, members, inputs):
         """one serial, timed pass; its predictions ARE the first batch's result (nothing is computed twice)"""
@@ -164,6 +245,7 @@ class MemberStreams:
             e1.record()
             e1.synchronize()
             cost.append(e0.elapsed_time(e1))
+            self.cost_ms[spec.name] = cost[-1]
         order = sorted(range(len(members)), key=lambda i: -cost[i])
         load = [0.0] * self.n
         assign: List[List[int]] = [[] for _ in range(self.n)]
@@ -171,20 +253,21 @@ class MemberStreams:
             j = min(range(self.n), key=lambda k: load[k])
             assign[j].append(i)
             load[j] += cost[i]
-        self.assign = assign
+        self._assign[tuple(spec.name for spec, _ in members)] = assign
         return out
 
     def predict_all(self, members, inputs) -> list:
         """inputs: {input_hw: tensor} produced on the current stream.  Returns member.predict() per member."""
         if self.n <= 1 or len(members) <= 1:
             return [model.predict(inputs[spec.input_hw]) for spec, model in members]
-        if self.assign is None or sum(len(a) for a in self.assign) != len(members):
+        assign = self._assign.get(tuple(spec.name for spec, _ in members))
+        if assign is None:
             return self._calibrate(members, inputs)
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
         out = [None] * len(members)
-        for st, idxs in zip(self.streams, self.assign):
+        for st, idxs in zip(self.streams, assign):
             if not idxs:
                 continue
             st.wait_event(ready)
@@ -196,6 +279,27 @@ class MemberStreams:
             done.record(st)
             main.wait_event(done)
         return out
+
+
+def measure_costs(members, raws: Sequence[bytes], dist=None, rank: int = 0) -> List[float]:
+    """ms per image of every member on a sample batch (JPEG byte strings), timed on rank 0 (a serial pass, the one
+    ``MemberStreams._calibrate`` makes) and broadcast so that every rank derives the SAME hybrid ShardPlan.  Set-up traffic
+    (one float per member), not part of the per-image data path."""
+    from . import pipeline
+    costs = torch.zeros((len(members),), dtype=torch.float64, device="cuda")
+    if rank == 0:
+        batch = pipeline.decode_jpegs(list(raws))
+        inputs = {}
+        for spec, _ in members:
+            if spec.input_hw not in inputs:
+                inputs[spec.input_hw] = batch.resized(spec.input_hw, spec.input_hw)
+        ms = MemberStreams(2)
+        ms._calibrate(members, inputs)          # warm-up: first-launch costs (module load, attribute calls)
+        ms._calibrate(members, inputs)
+        costs = torch.tensor([ms.cost_ms[spec.name] / max(len(raws), 1) for spec, _ in members], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.broadcast(costs, src=0)
+    return [float(v) for v in costs.cpu()]
 
 
 def default_streams() -> int:

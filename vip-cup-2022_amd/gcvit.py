@@ -10,6 +10,7 @@ from typing import Dict
 import torch
 
 from . import ops
+from .pipeline import keras_predict
 from .synth import ParamGen
 
 # models/gcvit/models/gcvit.py:10-43
@@ -141,6 +142,7 @@ class _Block:
         return ops.mlp(x, self.fc1, self.fc2, act="gelu", residual=x, ln=(self.n2.g, self.n2.b, LN_EPS))   # x + mlp(norm2(x))  (:80)
 
 
+@keras_predict
 class GCViT:
     def __init__(self, params: Dict[str, torch.Tensor], window_size, dim, depths, num_heads, mlp_ratio=3.0,
                  layer_scale=None, classes: int = 1, device="cuda"):

@@ -8,6 +8,7 @@ from typing import Dict
 import torch
 
 from . import ops
+from .pipeline import keras_predict
 from .synth import ParamGen
 
 LN_EPS = 1e-5   # common_layers.py:8,215-219
@@ -64,6 +65,7 @@ class _LN:
         return ops.layernorm(x, self.g, self.b, LN_EPS)
 
 
+@keras_predict
 class HorNet:
     def __init__(self, params: Dict[str, torch.Tensor], num_blocks, embed_dim, mlp_ratio=4, gn_split=(2, 3, 4, 5),
                  scale=0.3333333, classes: int = 1, first_strides: int = 2, device="cuda"):

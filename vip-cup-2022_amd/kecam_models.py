@@ -19,6 +19,7 @@ from typing import Dict
 import torch
 
 from . import ops
+from .pipeline import keras_predict
 from .synth import ParamGen, fold_bn
 
 PAD1 = (1, 1, 1, 1)
@@ -55,6 +56,7 @@ def _head(p, dev):
     return (p["predictions/kernel"].t().contiguous().to(dev, torch.float32), p["predictions/bias"].to(dev, torch.float32))
 
 
+@keras_predict
 class _Base:
     classes = 1
 

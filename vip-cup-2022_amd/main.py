@@ -40,6 +40,10 @@ def main(argv=None):
     ap.add_argument("--debug", type=int, default=0)         # main.py:82-83: first 100 images
     ap.add_argument("--tta", type=int, default=1)           # main.py:167: passes under apply_augment, averaged
     ap.add_argument("--tta-seed", type=int, default=0)
+    ap.add_argument("--shard", default="images", choices=["images", "members", "hybrid"],
+                    help="how N > 1 ranks split the (member, image-shard) grid: images = every rank all members on its image shard "
+                         "(MirroredStrategy's split, utils/device.py:7); members = rank r owns members r mod N and scores every "
+                         "image (one model per GPU); hybrid = LPT packing by measured ms/image.  One all-gather in every mode.")
     a = ap.parse_args(argv)
 
     import pandas as pd
@@ -71,7 +75,7 @@ def main(argv=None):
         names = names[:100]
     paths = [os.path.join(infer_path, n) for n in names]
 
-    members = []
+    manifest = []
     for name, dim, idx in json.load(open(a.ckpt_cfg)):           # main.py:171-198
         key = zoo.by_ckpt_name(name)
         if key is None:
@@ -80,9 +84,19 @@ def main(argv=None):
                     print(f"> SKIP {name}: graph not built in this round")
                 continue
             raise ValueError(f"manifest member {name} has no graph in vipcup_amd.zoo")
+        manifest.append((name, dim, idx, key))
+    plan = ensemble.ShardPlan("members" if a.shard == "members" else "images", len(manifest), world)
+    mine = {m for ms in plan.units[rank].values() for m in ms}   # members mode: a rank loads only the members it owns
+    members = []
+    for mi, (name, dim, idx, key) in enumerate(manifest):
         spec = zoo.MEMBERS[key]
         assert [spec.input_hw, spec.input_hw] == list(dim), (name, dim)
         ckpts = sorted(glob(os.path.join(HERE, "ckpts", name, "ckpt", "*.npz")))
+        if mi not in mine:
+            if not ckpts and not a.synthetic:
+                raise ValueError(f"no checkpoints under ckpts/{name}/ckpt (pass --synthetic for seeded synthetic weights)")
+            members.append((spec, None))
+            continue
         if ckpts:
             folds = [zoo.construct(spec, {k: torch.from_numpy(v) for k, v in np.load(c).items()}) for c in ckpts]
         elif a.synthetic:
@@ -101,8 +115,13 @@ def main(argv=None):
         return out
 
     t0 = time.time()
+    costs = None
+    if a.shard == "hybrid" and world > 1:
+        costs = ensemble.measure_costs(members, jpegs_for(0, min(len(paths), a.batch_size)), dist, rank)
+        if rank == 0:
+            print("> HYBRID PLAN:", ensemble.ShardPlan("hybrid", len(members), world, costs).describe())
     per_model = ensemble.score_files(jpegs_for, len(paths), members, a.batch_size, rank, world, dist,
-                                     tta=a.tta, tta_seed=a.tta_seed)
+                                     tta=a.tta, tta_seed=a.tta_seed, shard=a.shard, costs=costs)
     uniq, score, decision = ensemble.aggregate(names, per_model)
     if rank == 0:
         pd.DataFrame({"filename": uniq, "logit": decision}).to_csv(a.output_csv, index=False)  # main.py:143-145

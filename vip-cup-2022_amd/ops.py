@@ -187,19 +187,12 @@ def make_dense_weight(kernel_io: torch.Tensor, bias: Optional[torch.Tensor], dev
     return make_conv_weight(kernel_io.reshape(1, 1, *kernel_io.shape), bias, 1, device, None, pad_cout_to)
 
 
-def gemm_kernel_name(M: int, K: int, kh: int, kw: int, sh: int, sw: int, pad, groups: int, same_size: bool,
-                     act, act_post, has_res: bool, cin_g: int = 1 << 20) -> str:
-    """Which kernel vip_conv2d_nhwc_f16 dispatches to (mirror of the selection at the end of csrc/conv_igemm.hip;
-    used only to label profiler records)."""
-    pointwise = (groups == 1 and kh == 1 and kw == 1 and sh == 1 and sw == 1 and not any(pad) and same_size)
-    epi_ok = ((not has_res and act_post is None) or (has_res and act is None and act_post in (None, "relu")))
-    if pointwise and M <= 256 and not has_res and act_post is None:
-        return "rows_gemm_kernel"
-    if pointwise and epi_ok:
-        return "pw_gemm_kernel" if (K <= 256 and M >= 65536) else "pwk_gemm_kernel"
-    if epi_ok and (cin_g <= 16 or M >= 32768):
-        return "pwk_gemm_kernel"          # stems and every layer with >= 32 K pixels: im2col staging on the pointwise kernel
-    return "conv_igemm_kernel"
+def conv_kernel_name(d: "_abi.ConvDesc", has_residual: bool, has_gate: bool = False, has_w_lo: bool = False) -> Optional[str]:
+    """The kernel vip_conv2d_nhwc_f16 (/ _gated_ / _hilo_) launches for this descriptor - asked of the C dispatcher
+    itself (a dry run of the selection, vip_conv2d_kernel_name); None when the combination is not supported."""
+    buf = C.create_string_buffer(64)
+    st = _abi.lib().vip_conv2d_kernel_name(C.byref(d), int(has_residual), int(has_gate), int(has_w_lo), buf, 64)
+    return buf.value.decode() if st == 0 else None
 
 
 def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None,
@@ -215,40 +208,33 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
     B, H, W, ldx = x.shape
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     pt, pb, pl, pr = pad
+    Ho = (H + pt + pb - cw.kh) // sh + 1
+    Wo = (W + pl + pr - cw.kw) // sw + 1
+    d = _abi.ConvDesc(B=B, H=H, W=W, Cin=cw.cin, Cout=cw.cout, kh=cw.kh, kw=cw.kw, sh=sh, sw=sw, pt=pt, pl=pl,
+                      Ho=Ho, Wo=Wo, groups=cw.groups, ldx=ldx, cin_off=cin_off, ldy=cw.cout if out is None else out.shape[3],
+                      cout_off=cout_off, ldr=0 if residual is None else residual.shape[3], res_off=0, ldw=cw.ldw,
+                      act_pre=_act(act), act_post=_act(act_post))
     if gate is not None:
         _chk16(gate, "conv2d.gate")
         assert gate.shape == (B, 2, cw.cin) and ldx == cw.cin and cin_off == 0
-        foldable = gemm_kernel_name(1 << 20, 1 << 20, cw.kh, cw.kw, sh, sw, pad, cw.groups,
-                                    True, act, act_post, residual is not None) != "conv_igemm_kernel"
-        if _CALIB or not foldable or B * H * W * ldx * 2 >= 0xFFFF0000 - 2 * ldx:
+        if _CALIB or conv_kernel_name(d, residual is not None, has_gate=True) is None:
             x = scale_add_act(x, gate, None, None)
             gate = None
     if _CALIB and cw.err is not None:
         _bias_correct(cw, x[..., cin_off:cin_off + cw.cin])
-    Ho = (H + pt + pb - cw.kh) // sh + 1
-    Wo = (W + pl + pr - cw.kw) // sw + 1
     if out is None:
         out = torch.empty((B, Ho, Wo, cw.cout), dtype=torch.float16, device=x.device)
     else:
         _chk16(out, "conv2d.out")
         assert out.shape[:3] == (B, Ho, Wo), (out.shape, (B, Ho, Wo))
-    d = _abi.ConvDesc(B=B, H=H, W=W, Cin=cw.cin, Cout=cw.cout, kh=cw.kh, kw=cw.kw, sh=sh, sw=sw, pt=pt, pl=pl,
-                      Ho=Ho, Wo=Wo, groups=cw.groups, ldx=ldx, cin_off=cin_off, ldy=out.shape[3],
-                      cout_off=cout_off, ldr=0, res_off=0, ldw=cw.ldw, act_pre=_act(act), act_post=_act(act_post))
     if residual is not None:
         _chk16(residual, "conv2d.residual")
         assert residual.shape[:3] == (B, Ho, Wo) and residual.shape[3] >= cw.cout
-        d.ldr = residual.shape[3]
     tok = None
     if _PROF is not None:
         M = B * Ho * Wo
         kk = cw.kh * cw.kw * cw.alg_cin_g
-        name = gemm_kernel_name(M, cw.kh * cw.kw * cw.cin_g, cw.kh, cw.kw, sh, sw, pad, cw.groups, (Ho, Wo) == (H, W),
-                                act, act_post, residual is not None, cw.cin_g)
-        if gate is not None:
-            name = "pwk_gemm_kernel"
-        if cw.w_lo is not None:
-            name = "pw_gemm_kernel"
+        name = conv_kernel_name(d, residual is not None, gate is not None, cw.w_lo is not None) or "unsupported"
         tok = _PROF.start(name, 2.0 * M * cw.cout * kk,
                           2.0 * (B * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()))
     if cw.w_lo is not None:
@@ -283,7 +269,10 @@ def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Op
         ldr = cw.cout
     tok = None
     if _PROF is not None:
-        name = gemm_kernel_name(M, K, 1, 1, 1, 1, (0, 0, 0, 0), 1, True, act, act_post, residual is not None)
+        d = _abi.ConvDesc(B=M, H=1, W=1, Cin=K, Cout=cw.cout, kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Ho=1, Wo=1, groups=1, ldx=K,
+                          cin_off=0, ldy=cw.cout, cout_off=0, ldr=ldr, res_off=0, ldw=cw.ldw, act_pre=_act(act),
+                          act_post=_act(act_post))
+        name = conv_kernel_name(d, residual is not None) or "unsupported"
         tok = _PROF.start(name, 2.0 * M * cw.cout * K,
                           2.0 * (M * K + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()))
     st = _abi.lib().vip_gemm_bias_act_f16(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), M, cw.cout, K,

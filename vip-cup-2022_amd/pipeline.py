@@ -122,17 +122,174 @@ def apply_augment(x: torch.Tensor, hflip, vflip, gray) -> torch.Tensor:
     return out
 
 
-def build_dataset(paths: Sequence[str], batch_size: int, img_size: Tuple[int, int], device="cuda", threads: int = 0):
-    """Generator form of ``build_dataset(paths, labels=None, augment=False, repeat=False, shuffle=False)``
-    (dataset/dataset.py:64-102): yields fp16 NHWC batches ``[bs, H, W, 8]`` in path order; the last batch is
-    short (``drop_remainder=False``)."""
-    for i in range(0, len(paths), batch_size):
-        chunk = paths[i:i + batch_size]
-        raw = []
-        for p in chunk:
-            with open(p, "rb") as f:  # tf.io.read_file (:24)
-                raw.append(f.read())
-        yield decode_jpegs(raw, device, threads).resized(img_size[0], img_size[1])
+class Dataset:
+    """What ``build_dataset`` returns: an iterable of batches with the stream semantics of the reference's tf.data chain
+    ``from_tensor_slices(paths).map(decode)[.cache()][.repeat()][.shuffle(buf, seed)][.map(augment)].batch(bs, drop_remainder).prefetch()``
+    (dataset/dataset.py:87-101).  Element k of the stream is image ``k % n`` (pass ``k // n``) unless shuffled; batches run across
+    the repeat boundary exactly as ``repeat()`` before ``batch()`` makes them.  Each batch is an fp16 NHWC tensor
+    ``[bs, H, W, 8]`` resident on the GPU (channels 3..7 zero), or ``(batch, labels)`` when labels were given."""
+
+    def __init__(self, paths, labels, batch_size, cache, decode_fn, augment_fn, img_size, augment, repeat, shuffle,
+                 drop_remainder, seed, num_classes, device, threads):
+        self.paths = [os.fspath(p) for p in paths]
+        self.labels = None if labels is None else np.asarray(labels)
+        self.batch_size, self.cache, self.decode_fn, self.augment_fn = int(batch_size), bool(cache), decode_fn, augment_fn
+        self.img_size = (int(img_size[0]), int(img_size[1]))
+        self.augment, self.repeat, self.shuffle, self.drop_remainder = bool(augment), bool(repeat), int(shuffle or 0), bool(drop_remainder)
+        self.seed, self.num_classes, self.device, self.threads = int(seed), int(num_classes), device, threads
+        self._cached: Dict[int, torch.Tensor] = {}      # image index -> [H, W, 8] fp16 (``cache=True``: decoded once, kept in HBM)
+
+    def __len__(self):
+        """batches in one pass (tf.data cardinality of the un-repeated dataset)"""
+        n, bs = len(self.paths), self.batch_size
+        return n // bs if self.drop_remainder else -(-n // bs)
+
+    def _order(self):
+        """stream of (image index, pass) - repeat(), then a buffered shuffle like tf.data's (uniform pick from a buffer)"""
+        n = len(self.paths)
+
+        def base():
+            t = 0
+            while True:
+                for i in range(n):
+                    yield i, t
+                t += 1
+                if not self.repeat:
+                    return
+        if not self.shuffle:
+            yield from base()
+            return
+        rng = np.random.default_rng(self.seed)
+        buf = []
+        for item in base():
+            buf.append(item)
+            if len(buf) >= self.shuffle:
+                yield buf.pop(int(rng.integers(len(buf))))
+        while buf:
+            yield buf.pop(int(rng.integers(len(buf))))
+
+    def _host_stage(self, items):
+        """read + entropy-decode the images of one batch that are not cached (runs on the read-ahead thread)"""
+        todo = [i for i, _ in items if i not in self._cached]
+        todo = list(dict.fromkeys(todo))
+        if not todo:
+            return todo, None
+        if self.decode_fn is not None:                      # caller-supplied decoder: path -> float [H, W, 3] in [0, 1]
+            return todo, [np.asarray(self.decode_fn(self.paths[i]), dtype=np.float32) for i in todo]
+        raws = []
+        for i in todo:
+            with open(self.paths[i], "rb") as f:            # tf.io.read_file (dataset.py:24)
+                raws.append(f.read())
+        return todo, entropy_decode(raws, self.threads, pinned=torch.cuda.is_available())
+
+    def _device_stage(self, items, staged):
+        from . import ops
+        todo, host = staged
+        fresh: Dict[int, torch.Tensor] = {}
+        if todo:
+            if self.decode_fn is not None:
+                x = ops.to_device_nhwc8(torch.from_numpy(np.stack(host)), self.device)
+            else:
+                x = decode_entropy(host, self.device).resized(self.img_size[0], self.img_size[1])
+            fresh = {i: x[j] for j, i in enumerate(todo)}
+            if self.cache:
+                self._cached.update(fresh)
+        src = self._cached if self.cache else fresh
+        batch = torch.stack([src[i] if i in src else fresh[i] for i, _ in items])
+        if self.augment:
+            if self.augment_fn is not None:
+                batch = self.augment_fn(batch)
+            else:       # apply_augment (dataset/augment.py:153-182): seeded draws per (pass, image) - TF's RNG stream is not reproducible
+                from .ensemble import tta_flags
+                passes = max(t for _, t in items) + 1
+                fl = tta_flags(len(self.paths), passes, self.seed)
+                sel = np.stack([fl[t, i] for i, t in items])
+                batch = apply_augment(batch, sel[:, 0], sel[:, 1], sel[:, 2])
+        if self.labels is None:
+            return batch
+        lab = torch.as_tensor(self.labels[[i for i, _ in items]])
+        if self.num_classes > 1:                            # decode_with_labels (dataset.py:41-46)
+            lab = torch.nn.functional.one_hot(lab.long().reshape(-1), self.num_classes)
+        return batch, lab.to(torch.float32)
+
+    def __iter__(self):
+        from concurrent.futures import ThreadPoolExecutor
+
+        def batches():
+            cur = []
+            for item in self._order():
+                cur.append(item)
+                if len(cur) == self.batch_size:
+                    yield cur
+                    cur = []
+            if cur and not self.drop_remainder:
+                yield cur
+        it = batches()
+        with ThreadPoolExecutor(max_workers=1) as pool:     # prefetch(AUTO): the host stage of batch i+1 under the GPU work of batch i
+            nxt_items = next(it, None)
+            nxt = pool.submit(self._host_stage, nxt_items) if nxt_items is not None else None
+            while nxt_items is not None:
+                items, staged = nxt_items, nxt.result()
+                nxt_items = next(it, None)
+                nxt = pool.submit(self._host_stage, nxt_items) if nxt_items is not None else None
+                yield self._device_stage(items, staged)
+
+
+def build_dataset(paths, labels=None, batch_size=32, cache=True, decode_fn=None, augment_fn=None, dim=[200, 200],
+                  augment=True, repeat=True, shuffle=1024, cache_dir="", drop_remainder=False, CFG=None,
+                  device="cuda", threads: int = 0) -> Dataset:
+    """Same signature and stream semantics as the reference's ``build_dataset`` (dataset/dataset.py:64-102); the call
+    in main.py:89-98 works unchanged.  Like the reference, the image size comes from ``CFG.img_size`` (``dim`` is only the
+    fallback when no CFG is passed), ``CFG.seed`` seeds the shuffle, ``CFG.num_classes`` the label encoding; ``CFG.is_train``
+    is set as a side effect (:73).  ``cache`` keeps the decoded, resized batch elements resident in HBM (tf.data's in-memory
+    cache); ``cache_dir`` is created when given (:70-71) but nothing is written to it."""
+    if cache_dir != "" and cache is True:
+        os.makedirs(cache_dir, exist_ok=True)
+    img_size = tuple(dim)
+    seed, num_classes = 42, 1
+    if CFG is not None:
+        CFG.is_train = labels is not None
+        img_size = tuple(getattr(CFG, "img_size", dim))
+        seed = int(getattr(CFG, "seed", 42))
+        num_classes = int(getattr(CFG, "num_classes", 1))
+    return Dataset(paths, labels, batch_size, cache, decode_fn, augment_fn, img_size, augment, repeat, shuffle,
+                   drop_remainder, seed, num_classes, device, threads)
+
+
+def predict_dataset(predict_batch, dataset, steps=None, verbose=0) -> np.ndarray:
+    """``tf.keras.Model.predict(dataset, steps)`` (main.py:109): run ``predict_batch`` over ``ceil(steps)`` batches of the
+    iterable (Keras' data handler keeps stepping while ``step < steps``, so the reference's fractional
+    ``steps = max(tta * n / batch, 1)`` means its ceiling; ``None`` = until the dataset ends) and return the concatenated
+    predictions as a numpy array ``[sum of batch sizes, C]`` - the caller slices off what the repeat padded (main.py:110)."""
+    import math
+    limit = None if steps is None else int(math.ceil(float(steps)))
+    outs = []
+    for k, batch in enumerate(dataset):
+        if limit is not None and k >= limit:
+            break
+        x = batch[0] if isinstance(batch, (tuple, list)) else batch
+        outs.append(predict_batch(x))
+        if verbose:
+            print(f"{k + 1}/{limit if limit is not None else '?'} batches", end="\r", flush=True)
+    if verbose:
+        print()
+    if not outs:
+        return np.zeros((0, 1), dtype=np.float32)
+    return torch.cat([o.float() for o in outs], 0).cpu().numpy()
+
+
+def keras_predict(cls):
+    """Class decorator: ``model.predict`` keeps taking a resident batch tensor (-> tensor) and ALSO takes what
+    ``tf.keras.Model.predict`` takes in main.py:109 - a dataset iterable plus ``steps`` / ``verbose`` (-> numpy ``[n, C]``)."""
+    batch_predict = cls.predict
+
+    def predict(self, x, steps=None, verbose=0, **_keras_kwargs):
+        if isinstance(x, torch.Tensor):
+            return batch_predict(self, x)
+        return predict_dataset(lambda t: batch_predict(self, t), x, steps, verbose)
+    predict.__doc__ = batch_predict.__doc__
+    cls.predict = predict
+    return cls
 
 
 def calibration_batch(n: int = 16, seed: int = 20221, device="cuda") -> DecodedBatch:

@@ -11,6 +11,7 @@ from typing import Dict, List
 import torch
 
 from . import ops
+from .pipeline import keras_predict
 from .synth import ParamGen, fold_bn
 
 # models/resnet_rs/block_args.py:1-44 (depth -> [(input_filters, num_repeats)])
@@ -64,6 +65,7 @@ def synth_params(depth: int = 50, seed: int = 1006, classes: int = 1, se_ratio: 
     return g.p
 
 
+@keras_predict
 class ResNetRS:
     """Inference-only ResNet-RS.  ``params`` is a checkpoint dict (see synth_params)."""
 

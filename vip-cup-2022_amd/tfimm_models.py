@@ -11,6 +11,7 @@ from typing import Dict, Tuple
 import torch
 
 from . import ops
+from .pipeline import keras_predict
 from .synth import ParamGen
 
 LN_EPS = 1e-6  # norm_layer "layer_norm_eps_1e-6" (vit.py:55, convnext.py:124)
@@ -77,6 +78,7 @@ def vit_synth_params(cfg: ViTConfig, seed: int) -> Dict[str, torch.Tensor]:
     return g.p
 
 
+@keras_predict
 class ViT:
     def __init__(self, params: Dict[str, torch.Tensor], cfg: ViTConfig, device="cuda"):
         p, dev = params, device
@@ -178,6 +180,7 @@ def convnext_synth_params(cfg: ConvNeXtConfig, seed: int) -> Dict[str, torch.Ten
     return g.p
 
 
+@keras_predict
 class ConvNeXt:
     def __init__(self, params: Dict[str, torch.Tensor], cfg: ConvNeXtConfig, device="cuda"):
         p, dev = params, device

@@ -1,16 +1,29 @@
-"""Benchmark workloads: which ensemble members run, on what resident input, and how a step is timed.
+"""Benchmark workloads: which ensemble members run, on what input, how the (member, image-shard) grid is dealt to the
+ranks, and how a step is timed.
 
-Used by bench.py and __graft_entry__.smoke().  No oracle imports here (the CPU baseline lives in
+Used by bench.py, __graft_entry__.smoke() and tests/test_gpu_parity.py.  No oracle imports here (the CPU baseline lives in
 bench.py).
+
+A step (BASELINE.json config 5 / SURVEY.md section 8(d): "bytes in RAM -> scores"): the JPEG byte strings of one batch per
+image-shard, resident in host RAM -> host Huffman decode into a page-locked buffer (C++ threads, one batch of read-ahead
+on a worker thread as in ensemble.score_files) -> H2D -> GPU dequant / IDCT / upsample / colour -> bicubic resize + /255 per
+member resolution -> forward of the members this rank owns -> ONE all-gather of the score payloads -> ensemble mean.
+``resident=True`` is the round-1 variant: the step starts from decoded RGB u8 pixels already in HBM.
 """
-from typing import Dict, List, Optional
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Optional, Sequence
 
 import torch
 
 from . import ensemble, ops, pipeline
 from . import zoo
 
-DEFAULT = "ensemble"
+DEFAULT = "ensemble8"
+
+# ms per 256 images of each member alone on one MI355X (profiles/r01_members_v5.log; ViT-S from r01_configs_attention_v5.log):
+# the a-priori cost vector of the hybrid ShardPlan when nothing has been measured in-process yet
+MEMBER_MS_256 = {"convnext_tiny_in22k": 16.8, "gcvit_tiny": 9.3, "efficientnet_v1b4": 8.0, "resnest50": 6.5, "resnet_rs50": 6.2,
+                 "eca_nfnet_l0": 5.6, "efficientnet_v2t": 4.9, "vit_small_patch16_224": 5.0, "vit_tiny_patch16_224": 2.2}
 
 
 class KernelProfile:
@@ -41,59 +54,116 @@ class KernelProfile:
         return out
 
 
+def kernel_family(name: str) -> str:
+    """profiler record name (the kernel the C dispatcher reports) -> roofline family: the three instantiation groups of the
+    pointwise-GEMM pipeline (direct / LDS-staged / im2col) are one family, as in the rocprofv3 summaries."""
+    return "pwk_*" if name.startswith("pwk_") else name
+
+
 class Workload:
-    def __init__(self, name: str, members: List[str], batch: int, rank: int, world: int):
-        self.name = name
-        self.batch = batch
-        self.rank = rank
-        self.world = world
-        self.members = members
-        self.models = [zoo.build_member(m) for m in members]
-        # resident input: decoded 200x200 RGB uint8 pixels (what tf.image.decode_jpeg yields, dataset.py:28)
-        g = torch.Generator().manual_seed(1234 + rank)
-        rgb = torch.randint(0, 256, (batch, 200, 200, 3), generator=g, dtype=torch.uint8).cuda()
-        sizes = torch.tensor([[200, 200]] * batch, dtype=torch.int32, device="cuda")
-        self.batch_rgb = pipeline.DecodedBatch(rgb, sizes, [(200, 200)] * batch)
+    def __init__(self, name: str, members: List[str], batch: int, rank: int, world: int, shard: str = "images",
+                 resident: bool = False, jpegs: Optional[Sequence[bytes]] = None, models=None):
+        self.name, self.batch, self.rank, self.world, self.members = name, batch, rank, world, members
+        self.shard, self.resident = shard, resident
+        costs = [MEMBER_MS_256.get(m, 10.0 * zoo.MEMBERS[m].gmac_per_image / 4.0) for m in members]
+        self.plan = ensemble.ShardPlan(shard, len(members), world, costs)
+        if models is None:
+            mine = sorted({m for ms in self.plan.units[rank].values() for m in ms})
+            built = {m: zoo.build_member(members[m]) for m in mine}          # only what this rank's plan names is resident
+            models = [built.get(m, (zoo.MEMBERS[members[m]], None)) for m in range(len(members))]
+        self.models = models
+        # one synthetic batch (SURVEY.md section 8(d) generator), the same bytes for every image-shard: JPEG byte strings in host RAM
+        if jpegs is None:
+            from tools.make_synth import synth_jpeg
+            jpegs = [synth_jpeg(i) for i in range(batch)]
+        assert len(jpegs) == batch
+        self.jpegs = list(jpegs)
         self.scores = None
-        self._gather = None
         self.member_streams = ensemble.MemberStreams(ensemble.default_streams())
         self._serial = ensemble.MemberStreams(1)
+        self._pool = ThreadPoolExecutor(max_workers=1)
+        self._ahead = None
+        self._resident_batch = None
+        if resident:
+            self._resident_batch = pipeline.decode_jpegs(self.jpegs)
+        self.last_host_wait_ms = 0.0
 
+    # ---- input stage -------------------------------------------------------------------------------------------------
+    def _host_stage(self):
+        return pipeline.entropy_decode(self.jpegs, pinned=True)
+
+    def _next_batch(self) -> pipeline.DecodedBatch:
+        """decoded RGB u8 of the next image-shard: from HBM (resident) or through the JPEG path with one batch of read-ahead"""
+        if self.resident:
+            return self._resident_batch
+        if self._ahead is None:
+            self._ahead = self._pool.submit(self._host_stage)
+        staged = self._ahead.result()
+        self._ahead = self._pool.submit(self._host_stage)
+        return pipeline.decode_entropy(staged)
+
+    # ---- one step ----------------------------------------------------------------------------------------------------
     def step(self, dist=None, serial: bool = False):
-        """cast+resize+/255 per member resolution (dataset.py:31-38), score the resident batch with every
-        member, mean over members (main.py:142-143), all-gather across ranks."""
-        cache = {}
-        for spec, _ in self.models:
-            hw = spec.input_hw
-            if hw not in cache:
-                cache[hw] = self.batch_rgb.resized(hw, hw)
-        probs = (self._serial if serial else self.member_streams).predict_all(self.models, cache)
-        s = torch.stack(probs, 0).mean(0).reshape(-1)
-        if dist is not None and self.world > 1:
-            if self._gather is None:       # flat: the concatenation form every backend accepts (gloo rejects the stacked one)
-                self._gather = torch.empty((self.world * s.numel(),), dtype=s.dtype, device=s.device)
-            dist.all_gather_into_tensor(self._gather, s)
-            s = self._gather.view(self.world, -1)
-        self.scores = s
-        return s
+        if dist is None and self.world > 1:
+            raise RuntimeError("Workload.step: world > 1 needs the process group")
+        streams = self._serial if serial else self.member_streams
+        n_images = self.batch * self.world
+        local = {}
+        for s in sorted(self.plan.units[self.rank]):
+            midx = self.plan.units[self.rank][s]
+            sub = [self.models[m] for m in midx]
+            batch = self._next_batch()
+            cache = {}
+            for spec, _ in sub:
+                hw = spec.input_hw
+                if hw not in cache:
+                    cache[hw] = batch.resized(hw, hw)        # cast + bicubic + /255 (dataset.py:31-38)
+            for m, p in zip(midx, streams.predict_all(sub, cache)):
+                local[(s, m)] = ((1.0 - p[:, 0]) if p.shape[1] > 1 else p[:, 0]).float()      # main.py:113-114
+        full = ensemble.gather_plan_scores(self.plan, self.rank, n_images, local, dist if self.world > 1 else None,
+                                           torch.device("cuda"))
+        self.scores = full.mean(0)                           # ensemble mean per image (main.py:142-143)
+        return self.scores
+
+    def close(self):
+        if self._ahead is not None:
+            self._ahead.result()
+            self._ahead = None
+        self._pool.shutdown(wait=True)
 
     def config(self):
-        return {"workload": self.name, "members": self.members, "batch_per_gpu": self.batch,
-                "global_batch": self.batch * self.world,
-                "input": "decoded 200x200 RGB u8 resident in HBM -> bicubic resize per member resolution -> fp16 NHWC",
-                "parallelism": f"image-parallel dp{self.world}, all-gather of scores",
+        inp = ("decoded 200x200 RGB u8 resident in HBM" if self.resident else
+               "200x200 JPEG byte strings in host RAM -> host Huffman (pinned, 1 batch read-ahead) -> H2D -> GPU IDCT/colour")
+        par = {"images": f"image-parallel dp{self.world}", "members": f"member-parallel mp{self.world} (rank r owns members r mod N)",
+               "hybrid": f"hybrid LPT over {len(self.members)}x{self.world} (member, image-shard) units"}[self.shard]
+        return {"workload": self.name + ("-resident" if self.resident else ""), "members": self.members,
+                "batch_per_shard": self.batch, "global_batch": self.batch * self.world,
+                "input": inp + " -> bicubic resize + /255 per member resolution -> fp16 NHWC",
+                "parallelism": par + ", one all-gather of scores", "shard": self.shard,
                 "member_streams": self.member_streams.n}
 
-    def roofline(self, peak_tflops: float, peak_gbs: float):
-        """One instrumented step: per-kernel-family time from HIP events around each launch."""
+    # ---- roofline of the dominant kernel family -------------------------------------------------------------------------
+    def profile(self):
+        """One instrumented step on a single stream: per-launch HIP events on the launch stream."""
         prof = KernelProfile()
         ops.set_profiler(prof)
         try:
-            self.step(None, serial=True)      # one stream: per-launch HIP events see only their own kernel
+            self.step(None if self.world == 1 else _NoExchange(), serial=True)
         finally:
             ops.set_profiler(None)
-        summ = prof.summary()
-        self._summ = summ
+        raw = prof.summary()
+        fam: Dict[str, Dict[str, float]] = {}
+        for name, d in raw.items():
+            f = fam.setdefault(kernel_family(name), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "kernels": {}})
+            for k in ("launches", "ms", "flops", "bytes"):
+                f[k] += d[k]
+            f["kernels"][name] = d["launches"]
+        self._summ = fam
+        return fam
+
+    def roofline(self, peaks: Dict[str, float]):
+        """``peaks`` = {"mfma_tflops", "hbm_gbs"} vendor figures + optional {"mfma_tflops_measured", "hbm_gbs_measured"}."""
+        summ = getattr(self, "_summ", None) or self.profile()
         if not summ:
             return None
         fam = max(summ, key=lambda k: summ[k]["ms"])
@@ -102,12 +172,23 @@ class Workload:
         tf = d["flops"] / sec / 1e12
         gbs = d["bytes"] / sec / 1e9
         intensity = d["flops"] / max(d["bytes"], 1.0)
-        common = {"kernel": fam, "traffic": _pmc_traffic(fam), "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/)",
-                  "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "launches": d["launches"],
-                  "avg_launch_ms": d["ms"] / d["launches"]}
-        if intensity * peak_gbs * 1e9 >= peak_tflops * 1e12:
-            return {"bound": "mfma", "achieved": tf, "peak": peak_tflops, "unit": "TFLOP/s", "frac": tf / peak_tflops, **common}
-        return {"bound": "hbm", "achieved": gbs, "peak": peak_gbs, "unit": "GB/s", "frac": gbs / peak_gbs, **common}
+        pk_t, pk_b = peaks["mfma_tflops"], peaks["hbm_gbs"]
+        common = {"kernel": fam, "kernels": d["kernels"], "traffic": _pmc_traffic(fam),
+                  "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/)",
+                  "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                  "algorithmic_flops_per_launch": d["flops"] / d["launches"], "launches": d["launches"],
+                  "avg_launch_ms": d["ms"] / d["launches"], "hbm_gbs": gbs, "hbm_frac": gbs / pk_b, "mfma_tflops": tf,
+                  "mfma_frac": tf / pk_t}
+        mt, mb = peaks.get("mfma_tflops_measured"), peaks.get("hbm_gbs_measured")
+        if intensity * pk_b * 1e9 >= pk_t * 1e12:
+            out = {"bound": "mfma", "achieved": tf, "peak": pk_t, "unit": "TFLOP/s", "frac": tf / pk_t, **common}
+            if mt:
+                out.update(peak_measured=mt, frac_of_measured=tf / mt)
+        else:
+            out = {"bound": "hbm", "achieved": gbs, "peak": pk_b, "unit": "GB/s", "frac": gbs / pk_b, **common}
+            if mb:
+                out.update(peak_measured=mb, frac_of_measured=gbs / mb)
+        return out
 
     def extra(self):
         summ = getattr(self, "_summ", None)
@@ -119,19 +200,67 @@ class Workload:
                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
 
 
+class _NoExchange:
+    """stand-in process group for the instrumented (single-rank) step of a multi-rank run: the gather is skipped"""
+
+    @staticmethod
+    def all_gather_into_tensor(out, inp):
+        out.view(-1, inp.numel())[:] = inp
+
+
 def _pmc_traffic(fam: str):
     """HBM bytes per launch of a kernel family from the committed PMC summary of this bench command
     (tools/pmc_traffic.py over `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes), or None."""
+    import glob
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_hbm_traffic_pmc.json")
-    try:
-        return json.load(open(path))[fam]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    key = "pwk_gemm_kernel" if fam == "pwk_*" else fam
+    for path in sorted(glob.glob(os.path.join(root, "r*_hbm_traffic_pmc.json")), reverse=True):
+        try:
+            return json.load(open(path))[key]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+    return None
 
 
-def build(name: str, batch: int, rank: int = 0, world: int = 1) -> Workload:
+def measure_peaks(ms_budget: float = 50.0) -> Dict[str, float]:
+    """On-box probes (about ``ms_budget`` ms each): HBM copy bandwidth (16 B per lane, 2 x 1 GiB of traffic per launch) and
+    the fp16 MFMA issue rate (v_mfma_f32_16x16x32_f16 back to back on every SIMD) - SURVEY.md section 8(d)."""
+    import ctypes as C
+    from . import _abi
+    lib = _abi.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = 1 << 30
+    src = torch.empty((nbytes,), dtype=torch.uint8, device="cuda").random_(0, 255)
+    dst = torch.empty_like(src)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    t_copy = timed(lambda: _abi.check(lib.vip_microbench_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), "vip_microbench_copy"),
+                   max(3, int(ms_budget / 0.4)))
+    sink = torch.zeros((16,), dtype=torch.float32, device="cuda")
+    flops = C.c_double(0.0)
+    iters = 2000
+    t_mfma = timed(lambda: _abi.check(lib.vip_microbench_mfma_f16(sink.data_ptr(), iters, C.byref(flops), st), "vip_microbench_mfma_f16"),
+                   max(3, int(ms_budget / 0.3)))
+    del src, dst
+    return {"hbm_gbs_measured": 2.0 * nbytes / (t_copy * 1e-3) / 1e9, "mfma_tflops_measured": flops.value / (t_mfma * 1e-3) / 1e12}
+
+
+def build(name: str, batch: int, rank: int = 0, world: int = 1, shard: str = "images", resident: bool = False,
+          jpegs: Optional[Sequence[bytes]] = None) -> Workload:
+    if name.endswith("-resident"):
+        name, resident = name[:-len("-resident")], True
     if name == "ensemble":
         members = zoo.ENSEMBLE
     elif name == "ensemble8":
@@ -140,4 +269,4 @@ def build(name: str, batch: int, rank: int = 0, world: int = 1) -> Workload:
         members = zoo.ENSEMBLE4
     else:
         members = [name]
-    return Workload(name, members, batch, rank, world)
+    return Workload(name, list(members), batch, rank, world, shard, resident, jpegs)

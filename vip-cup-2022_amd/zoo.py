@@ -159,12 +159,33 @@ def by_ckpt_name(ckpt_name: str):
     return None
 
 
-class FoldMean:
-    """mean over the fold checkpoints of one member (main.py:101-121)"""
+def _fold_mean_cls():
+    from .pipeline import keras_predict
 
-    def __init__(self, folds):
-        self.folds = folds
+    @keras_predict
+    class FoldMean:
+        """mean over the fold checkpoints of one member (main.py:101-121)"""
 
-    def predict(self, x):
-        ps = [m.predict(x) for m in self.folds]
-        return ps[0] if len(ps) == 1 else sum(ps) / float(len(ps))
+        def __init__(self, folds):
+            self.folds = folds
+
+        def predict(self, x):
+            ps = [m.predict(x) for m in self.folds]
+            return ps[0] if len(ps) == 1 else sum(ps) / float(len(ps))
+    return FoldMean
+
+
+FoldMean = _fold_mean_cls()
+
+
+def load_model(path: str, compile: bool = False):
+    """Counterpart of ``tf.keras.models.load_model(path, compile=False)`` (main.py:107) for this build's checkpoint format:
+    ``path`` = ``.../ckpts/<member directory>/ckpt/<fold>.npz`` (a flat dict of Keras-named arrays).  The member graph is picked from
+    the directory name exactly as the reference picks its batch size from it (main.py:70-71,85); the returned object has the
+    ``predict(dataset, steps, verbose) -> np.ndarray [n, C]`` of a Keras model."""
+    model_name = os.path.basename(os.path.dirname(os.path.dirname(os.path.abspath(path))))
+    key = by_ckpt_name(model_name)
+    if key is None:
+        raise ValueError(f"load_model: no graph for checkpoint directory {model_name!r}")
+    spec = MEMBERS[key]
+    return construct(spec, {k: torch.from_numpy(v) for k, v in np.load(path).items()})
