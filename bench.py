@@ -55,6 +55,11 @@ def parse():
     return ap.parse_args()
 
 
+def note(msg: str):
+    """progress on stderr (stdout carries only the JSON line)"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def host_cores() -> int:
     try:
         return len(os.sched_getaffinity(0))
@@ -92,10 +97,12 @@ def cpu_baseline(wl, timed_batches: int):
             for m in wl.members:
                 refs[m].predict_logits(m, params[m], inputs[zoo.MEMBERS[m].input_hw])
 
+    note(f"cpu_baseline: {threads} threads, batch {bs}, 1 discarded + {timed_batches} timed batches x {len(wl.members)} members")
     one_batch()                                  # discarded (tfimm/utils/profile.py:30-42)
     t0 = time.perf_counter()
-    for _ in range(timed_batches):
+    for i in range(timed_batches):
         one_batch()
+        note(f"cpu_baseline: batch {i + 1}/{timed_batches} done, {time.perf_counter() - t0:.0f} s")
     dt = time.perf_counter() - t0
     return {"value": timed_batches * bs / dt, "unit": "images/sec", "cores": threads, "kind": "port",
             "sample": f"{timed_batches} timed batches of {bs} synthetic JPEGs (1 discarded) x {len(wl.members)} members: Pillow decode + "
@@ -150,8 +157,14 @@ def main():
     from vipcup_amd import workloads
 
     name = a.workload if a.workload != "auto" else workloads.DEFAULT
+    if rank == 0:
+        note(f"building workload {name} (members + bias calibration)")
     wl = workloads.build(name, batch=a.batch, rank=rank, world=world, shard=a.shard)
+    if rank == 0:
+        note(f"timing {a.warmup} + {a.steps} steps")
     dt = timed_steps(wl, dist, a.steps, a.warmup)
+    if rank == 0:
+        note(f"{a.batch * world * a.steps / dt:.0f} images/s, {dt / a.steps * 1e3:.2f} ms/step")
 
     # the metric's "inputs already resident in HBM" form of the same step, for the record (never `value` here)
     resident = None
@@ -164,6 +177,7 @@ def main():
 
     roof, peaks = None, None
     if rank == 0:
+        note("peak probes + instrumented step")
         peaks = {"mfma_tflops": PEAK_MFMA_F16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS}
         peaks.update(workloads.measure_peaks())
         roof = wl.roofline(peaks)

@@ -239,6 +239,36 @@ def test_dense_pointwise_modes(M, K, N, mode, report):
     check(report, f"dense-pointwise {mode} {M}x{K}x{N}", got, ref)
 
 
+# the LDS-DMA deep-K kernel (csrc/gemm8p.hpp: 256 x 256 x 64 tiles, K % 64 == 0, N % 256 == 0, >= 128 tiles): ragged M, 2-12 channel
+# tiles, short and long K loops, every epilogue family; the dispatcher must really pick it
+@pytest.mark.parametrize("mode", ["gelu", "res", "none"])
+@pytest.mark.parametrize("M,K,N", [(33017, 384, 512), (20000, 1536, 768), (16640, 768, 3072), (65536 + 5, 448, 256), (8500, 3072, 1024)])
+def test_dense_gemm8p(M, K, N, mode, report):
+    ops = _ops()
+    from vipcup_amd import _abi
+    g = torch.Generator().manual_seed(M + K + N)
+    x = h(torch.randn(M, K, generator=g))
+    w = h(torch.randn(K, N, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    cw = ops.make_dense_weight(w, b)
+    d = _abi.ConvDesc(B=M, H=1, W=1, Cin=K, Cout=N, kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Ho=1, Wo=1, groups=1, ldx=K, cin_off=0, ldy=N,
+                      cout_off=0, ldr=N if mode == "res" else 0, res_off=0, ldw=cw.ldw, act_pre=3 if mode == "gelu" else 0, act_post=0)
+    assert ops.conv_kernel_name(d, mode == "res") == "gemm8p_kernel"
+    if mode == "res":
+        res = h(torch.randn(M, N, generator=g))
+        ref = R.dense(x, w, b) + res
+        got = ops.dense(dev(x), cw, residual=dev(res))
+    else:
+        act = None if mode == "none" else mode
+        ref = R.act(R.dense(x, w, b), act)
+        got = ops.dense(dev(x), cw, act=act)
+    torch.cuda.synchronize()
+    check(report, f"dense-gemm8p {mode} {M}x{K}x{N}", got, ref)
+    got2 = ops.dense(dev(x), cw, act=None if mode != "gelu" else "gelu", residual=dev(res) if mode == "res" else None)
+    torch.cuda.synchronize()
+    assert torch.equal(got, got2), "two launches on the same operands must agree bit for bit (no race in the DMA ring)"
+
+
 # fused MLP (hidden tensor in registers): LDS-resident (C 64/96) and streamed (C 192) weights, M tails, with/without residual, vs two fp32 denses
 @pytest.mark.parametrize("use_ln", [False, True])
 @pytest.mark.parametrize("M,C,hid,use_res", [(8192, 96, 384, True), (20011, 96, 384, False), (9000, 64, 256, True),

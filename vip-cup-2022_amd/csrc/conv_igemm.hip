@@ -979,6 +979,8 @@ int launch_pwk_conv(const ConvArgs& a0, int mode, int groups, hipStream_t s) {
     return vip_launch_status("vip_conv2d_nhwc_f16(pwk-im2col)");
 }
 
+#include "gemm8p.hpp"
+
 // ---- Dense / 1x1 layers with at most 256 rows (the squeeze-excite and ECA layers: M = batch) ------------------------
 // On the tile kernels such a layer is ONE m-block: 2..16 workgroups walk K chunk by chunk behind a barrier each, 30-100
 // us of pure latency while the chip idles.  Here a workgroup owns 16 output channels for all rows, both MFMA operands
@@ -1177,6 +1179,11 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
         }
         VIP_REQUIRE(!y_lo_off, VIP_ERR_UNSUPPORTED, "vip_gemm_split_f16: at most 256 rows, N %% 4 == 0");
         if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) VIP_PICK("pw_gemm_kernel", launch_pw_k<4>(a, mode, s));
+        // deep K, wide N: the LDS-DMA kernel (gemm8p.hpp).  VIP_G8P_MINK: smallest K it takes (0 = never).
+        static const int g8_min_k = getenv("VIP_G8P_MINK") ? atoi(getenv("VIP_G8P_MINK")) : 384;
+        if (mode >= 0 && g8_min_k > 0 && !gate && a.K >= g8_min_k && gemm8p_eligible(a) && cout_g % 256 == 0 &&
+            (long)((M + 255) / 256) * (cout_g / 256) >= 128)
+            VIP_PICK("gemm8p_kernel", launch_gemm8p(a, mode, s));
         if (mode >= 0 && (pw_mode & 2) && a.x_span_bytes < 0xFFFFFFF0L) {
             // (a 64 x 256 wave tile at one wave per SIMD - NG = 4 - measured 15-40 % slower than NG = 2 at two)
             static const int xl_min_k = getenv("VIP_PWK_XLK") ? atoi(getenv("VIP_PWK_XLK")) : 768;
