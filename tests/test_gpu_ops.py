@@ -441,6 +441,39 @@ def test_window_attention(ws, heads, nW, global_q, report):
     check(report, f"window_attn ws{ws} heads{heads} nW{nW} global={global_q}", got, ref, tol=3e-3)
 
 
+@pytest.mark.parametrize("B,heads,nW,global_q", [(128, 8, 1, False), (131, 8, 1, True), (40, 8, 2, False), (70, 4, 2, True)])
+def test_window_attention_pipelined(B, heads, nW, global_q, report):
+    """ws 14 with >= 1024 (window, head) items: the persistent LDS-DMA kernel (window_attn_pipe_kernel) - 2..5 items per workgroup,
+    item counts that are not a multiple of the grid, several windows per image, global query; and bit-identical to the one-item
+    kernel (VIP_ATTN_PIPE only changes the schedule) and to itself across launches (no race in the DMA double buffer)."""
+    ops = _ops()
+    ws, C, hd = 14, heads * 32, 32
+    Hp = Wp = ws * nW
+    assert B * nW * nW * heads >= 1024
+    g = torch.Generator().manual_seed(B + heads * 10 + nW)
+    nq = 2 if global_q else 3
+    qkv = h(torch.randn(B, Hp, Wp, nq * C, generator=g))
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5
+    qg = h(torch.randn(B, ws, ws, C, generator=g)) if global_q else None
+    win = R.window_partition(qkv, ws).reshape(-1, ws * ws, nq, heads, hd).permute(2, 0, 3, 1, 4)
+    B_ = win.shape[1]
+    if global_q:
+        k, v = win[0], win[1]
+        q = torch.repeat_interleave(qg, B_ // B, dim=0).reshape(B_, ws * ws, heads, hd).permute(0, 2, 1, 3)
+    else:
+        q, k, v = win[0], win[1], win[2]
+    o = gcvit_ref.window_attention_core(q, k, v, table, ws, hd ** -0.5)
+    ref = R.window_reverse(o.permute(0, 2, 1, 3).reshape(B_, ws * ws, C), ws, Hp, Wp, C)
+    qd, gd, td = dev(qkv), None if qg is None else dev(qg).reshape(B, ws * ws, C), table.cuda()
+    got = ops.window_attention(qd, gd, td, heads, ws, hd ** -0.5)
+    torch.cuda.synchronize()
+    check(report, f"window_attn pipelined B{B} heads{heads} nW{nW} global={global_q}", got, ref, tol=3e-3)
+    for _ in range(3):
+        again = ops.window_attention(qd, gd, td, heads, ws, hd ** -0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(got, again)
+
+
 def test_window_attention_softmax_spike(report):
     """One key dominating one query (large logit) must not overflow and must pick that key's value."""
     ops = _ops()

@@ -7,6 +7,8 @@ SHAPES = [(2509056, 384, 96), (2509056, 96, 384), (614656, 768, 192), (614656, 1
           (147456, 384, 1536), (36864, 3072, 768), (36864, 768, 3072), (50176, 768, 256), (50176, 256, 768),
           (802816, 192, 64), (802816, 64, 192), (640000, 256, 64), (640000, 64, 256), (160000, 512, 128),
           (200704, 384, 128), (43264, 1024, 256), (12544, 1536, 512), (3211264, 144, 24)]
+if "--deep" in sys.argv:      # the compute-bound shapes only (K >= 384)
+    SHAPES = [s for s in SHAPES if s[2] >= 384] + [(43264, 1536, 384), (43264, 256, 1024), (12544, 2048, 512), (50176, 768, 3072)]
 for M, N, K in SHAPES:
     g = torch.Generator().manual_seed(0)
     x = torch.randn((M, K), generator=g, dtype=torch.float16).cuda() if M * K < 3e8 else torch.randn((M, K), dtype=torch.float16, device="cuda")

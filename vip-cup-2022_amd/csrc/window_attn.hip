@@ -24,6 +24,7 @@
 // (conflict-free ds_read_b128 fragment reads); V 32-byte halves swapped on rows with bit 2 set
 // (conflict-free transposed reads).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -69,124 +70,19 @@ __device__ __forceinline__ int k_slot(int row, int ch) {
     return ch ^ ((0x78 >> (q * 2)) & 3);  // pi = {0,2,3,1}
 }
 
+// One 16-query tile of one (window, head) item: S^T = K Q^T, bias, softmax, O^T = V^T P^T, store.  Shared by both kernels.
 template <int WS, int P, int LOG2P, int WPI>
-__global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
+__device__ __forceinline__ void win_query_tile(const WinArgs& a, const U4H8& qfrag, const char* k_lds, const char* v_lds,
+                                               const float* tb, int qt, int l15, int g, bool item_ok, long img_pix, int wy,
+                                               int wx, int head) {
     using Cfg = WinCfg<WS, P, LOG2P, WPI>;
-    constexpr int RP = Cfg::RP, NKT = Cfg::NKT, NQT = Cfg::NQT, QPW = Cfg::QPW;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int slot = wave / WPI;
-    const int lt = tid - slot * WPI * 64;
-    // XCD-aware block order: consecutive logical blocks (the heads of one window: neighbouring 64-byte slices of the
-    // same 128-byte lines) run on the same XCD and share its L2, instead of each XCD fetching the line for itself
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int item = bid * Cfg::IPW + slot;
-    const bool item_ok = item < a.items;
-    if (!item_ok) item = a.items - 1;
-    const int head = item % a.heads;
-    int wq = item / a.heads;
-    const int wx = wq % a.nWx;
-    wq /= a.nWx;
-    const int wy = wq % a.nWy;
-    const int b = wq / a.nWy;
-
-    char* base = smem + slot * Cfg::ITEM_BYTES;
-    char* k_lds = base + Cfg::K_OFF;
-    char* v_lds = base + Cfg::V_OFF;
-    float* tb = reinterpret_cast<float*>(base + Cfg::T_OFF);
-
-    const int ldq = a.nq * a.C;
-    const long img_pix = (long)b * a.Hp * a.Wp;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int wi = wave % WPI;
-
-    // ---- Q fragments of this wave's query tiles, straight from global (issued first: longest latency) ----
-    U4H8 qf[QPW];
-#pragma unroll
-    for (int i = 0; i < QPW; ++i) {
-        const int qn = (wi + i * WPI) * 16 + l15;  // dense token index ty*WS + tx
-        const int qy = qn / WS, qx = qn - qy * WS;
-        const bool valid = qn < WS * WS;
-        const long pix = img_pix + (long)(wy * WS + qy) * a.Wp + (wx * WS + qx);
-        const f16* src = (a.nq == 2) ? a.qg + ((long)b * WS * WS + qy * WS + qx) * a.C + head * 32 + g * 8
-                                     : a.qkv + pix * ldq + head * 32 + g * 8;
-        src = valid ? src : a.qkv;
-        const uint4 v = *reinterpret_cast<const uint4*>(src);
-        qf[i].u = valid ? v : make_uint4(0, 0, 0, 0);
-    }
-
-    // ---- stage K / V (re-indexed, zero-padded, swizzled) and the head's bias table.  All global loads
-    // are UNCONDITIONAL (masked lanes read a safe address and are zeroed afterwards) and issued back to
-    // back before the first LDS write: a load inside an `if` costs a full memory round trip each. ----
-    constexpr int NSLOT = 2 * RP * 4, NTHR = WPI * 64, NIT = (NSLOT + NTHR - 1) / NTHR;
-    {
-        uint4 st[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int s = lt + it * NTHR;
-            const int arr = s / (RP * 4);  // 0 = K, 1 = V
-            const int rem = s - arr * (RP * 4);
-            const int row = rem >> 2, ch = rem & 3;
-            const int ty = row >> LOG2P, tx = row & (P - 1);
-            const bool valid = (s < NSLOT) & (ty < WS) & (tx < WS);
-            const long pix = img_pix + (long)(wy * WS + ty) * a.Wp + (wx * WS + tx);
-            const f16* src = a.qkv + pix * ldq + (a.nq - 2 + arr) * a.C + head * 32 + ch * 8;
-            src = valid ? src : a.qkv;
-            const uint4 v = *reinterpret_cast<const uint4*>(src);
-            st[it] = valid ? v : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int s = lt + it * NTHR;
-            const int arr = s / (RP * 4);
-            const int rem = s - arr * (RP * 4);
-            const int row = rem >> 2, ch = rem & 3;
-            if (s < NSLOT) {
-                const int pch = (arr == 0) ? k_slot(row, ch) : (ch ^ (((row >> 2) & 1) << 1));
-                *reinterpret_cast<uint4*>((arr == 0 ? k_lds : v_lds) + row * Cfg::ROWB + pch * 16) = st[it];
-            }
-        }
-    }
-    {
-        constexpr int TIT = (Cfg::TB_FLOATS + NTHR - 1) / NTHR;
-        float tv[TIT];
-#pragma unroll
-        for (int it = 0; it < TIT; ++it) {
-            const int i = lt + it * NTHR;
-            const int e = i - Cfg::TOFF;
-            const int ry = e / Cfg::TW, rx = e - ry * Cfg::TW;
-            const bool in_tab = (i >= Cfg::TOFF) & (i < Cfg::TB_FLOATS) & (rx < Cfg::TROWS);
-            const int gi = in_tab ? (ry * Cfg::TROWS + rx) * a.heads + head : 0;
-            const float t = a.table[gi];
-            tv[it] = in_tab ? t * a.inv_scale : (i < Cfg::TOFF ? -1.0e30f : 0.f);
-        }
-#pragma unroll
-        for (int it = 0; it < TIT; ++it) {
-            const int i = lt + it * NTHR;
-            if (i < Cfg::TB_FLOATS) tb[i] = tv[it];
-        }
-    }
-    __syncthreads();
-
+    constexpr int NKT = Cfg::NKT;
     const float sc = a.scale_log2e;
     // lane-dependent part of the key term 2k' - kx  (k' = 16t + 4g + r)
     const int lane_term = (P == 16) ? 4 * g : (g >> 1) * Cfg::TW + 4 * (g & 1);
     // LDS byte offsets of this lane's fragment reads
     const int tr_q = l15 >> 2, tr_p = l15 & 3;
-
-#pragma unroll
-    for (int i = 0; i < QPW; ++i) {
-        const int qt = wi + i * WPI;
-        if (qt >= NQT) break;  // wave-uniform
+    {
         const int qn = qt * 16 + l15;
 
         // S^T tiles: rows = keys 16t + 4g + r, column = this lane's query.  The relative-position bias (stored as
@@ -202,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
             const int row = t * 16 + l15;
             U4H8 kf;
             kf.u = *reinterpret_cast<const uint4*>(k_lds + row * Cfg::ROWB + k_slot(row, g) * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf.h, qf[i].h, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf.h, qfrag.h, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -317,6 +213,299 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
 }
 
 template <int WS, int P, int LOG2P, int WPI>
+__global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
+    using Cfg = WinCfg<WS, P, LOG2P, WPI>;
+    constexpr int RP = Cfg::RP, NKT = Cfg::NKT, NQT = Cfg::NQT, QPW = Cfg::QPW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int slot = wave / WPI;
+    const int lt = tid - slot * WPI * 64;
+    // XCD-aware block order: consecutive logical blocks (the heads of one window: neighbouring 64-byte slices of the
+    // same 128-byte lines) run on the same XCD and share its L2, instead of each XCD fetching the line for itself
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int item = bid * Cfg::IPW + slot;
+    const bool item_ok = item < a.items;
+    if (!item_ok) item = a.items - 1;
+    const int head = item % a.heads;
+    int wq = item / a.heads;
+    const int wx = wq % a.nWx;
+    wq /= a.nWx;
+    const int wy = wq % a.nWy;
+    const int b = wq / a.nWy;
+
+    char* base = smem + slot * Cfg::ITEM_BYTES;
+    char* k_lds = base + Cfg::K_OFF;
+    char* v_lds = base + Cfg::V_OFF;
+    float* tb = reinterpret_cast<float*>(base + Cfg::T_OFF);
+
+    const int ldq = a.nq * a.C;
+    const long img_pix = (long)b * a.Hp * a.Wp;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wi = wave % WPI;
+
+    // ---- Q fragments of this wave's query tiles, straight from global (issued first: longest latency) ----
+    U4H8 qf[QPW];
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) {
+        const int qn = (wi + i * WPI) * 16 + l15;  // dense token index ty*WS + tx
+        const int qy = qn / WS, qx = qn - qy * WS;
+        const bool valid = qn < WS * WS;
+        const long pix = img_pix + (long)(wy * WS + qy) * a.Wp + (wx * WS + qx);
+        const f16* src = (a.nq == 2) ? a.qg + ((long)b * WS * WS + qy * WS + qx) * a.C + head * 32 + g * 8
+                                     : a.qkv + pix * ldq + head * 32 + g * 8;
+        src = valid ? src : a.qkv;
+        const uint4 v = *reinterpret_cast<const uint4*>(src);
+        qf[i].u = valid ? v : make_uint4(0, 0, 0, 0);
+    }
+
+    // ---- stage K / V (re-indexed, zero-padded, swizzled) and the head's bias table.  All global loads
+    // are UNCONDITIONAL (masked lanes read a safe address and are zeroed afterwards) and issued back to
+    // back before the first LDS write: a load inside an `if` costs a full memory round trip each. ----
+    constexpr int NSLOT = 2 * RP * 4, NTHR = WPI * 64, NIT = (NSLOT + NTHR - 1) / NTHR;
+    {
+        uint4 st[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int s = lt + it * NTHR;
+            const int arr = s / (RP * 4);  // 0 = K, 1 = V
+            const int rem = s - arr * (RP * 4);
+            const int row = rem >> 2, ch = rem & 3;
+            const int ty = row >> LOG2P, tx = row & (P - 1);
+            const bool valid = (s < NSLOT) & (ty < WS) & (tx < WS);
+            const long pix = img_pix + (long)(wy * WS + ty) * a.Wp + (wx * WS + tx);
+            const f16* src = a.qkv + pix * ldq + (a.nq - 2 + arr) * a.C + head * 32 + ch * 8;
+            src = valid ? src : a.qkv;
+            const uint4 v = *reinterpret_cast<const uint4*>(src);
+            st[it] = valid ? v : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int s = lt + it * NTHR;
+            const int arr = s / (RP * 4);
+            const int rem = s - arr * (RP * 4);
+            const int row = rem >> 2, ch = rem & 3;
+            if (s < NSLOT) {
+                const int pch = (arr == 0) ? k_slot(row, ch) : (ch ^ (((row >> 2) & 1) << 1));
+                *reinterpret_cast<uint4*>((arr == 0 ? k_lds : v_lds) + row * Cfg::ROWB + pch * 16) = st[it];
+            }
+        }
+    }
+    {
+        constexpr int TIT = (Cfg::TB_FLOATS + NTHR - 1) / NTHR;
+        float tv[TIT];
+#pragma unroll
+        for (int it = 0; it < TIT; ++it) {
+            const int i = lt + it * NTHR;
+            const int e = i - Cfg::TOFF;
+            const int ry = e / Cfg::TW, rx = e - ry * Cfg::TW;
+            const bool in_tab = (i >= Cfg::TOFF) & (i < Cfg::TB_FLOATS) & (rx < Cfg::TROWS);
+            const int gi = in_tab ? (ry * Cfg::TROWS + rx) * a.heads + head : 0;
+            const float t = a.table[gi];
+            tv[it] = in_tab ? t * a.inv_scale : (i < Cfg::TOFF ? -1.0e30f : 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < TIT; ++it) {
+            const int i = lt + it * NTHR;
+            if (i < Cfg::TB_FLOATS) tb[i] = tv[it];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) {
+        const int qt = wi + i * WPI;
+        if (qt >= NQT) break;  // wave-uniform
+        win_query_tile<WS, P, LOG2P, WPI>(a, qf[i], k_lds, v_lds, tb, qt, l15, g, item_ok, img_pix, wy, wx, head);
+    }
+}
+
+// ---- ws = 14, persistent + pipelined ----------------------------------------------------------------------------------
+// The kernel above is a load phase followed by a compute phase per workgroup; with HBM time (~18 us for the 103 MB of level 2
+// at B = 256) about equal to the VALU + MFMA time (~20 us) and every resident workgroup in the same phase, the two add up
+// (42 us).  Here a workgroup walks several (window, head) items of ONE head (bias table staged once) and the K / V images of
+// item k+1 are written into a second LDS buffer by LDS-DMA (buffer_load_dwordx4 ... lds: no registers, no ds_write pass) while
+// item k is being computed, so fetch and math of the same workgroup overlap.  The re-indexing (row' = 16 ty + tx, two
+// zero-padded slots per token row) and both swizzles are applied on the SOURCE side: the DMA fills LDS lane-linearly
+// (16 rows x 64 B per wave instruction = one token row), lane (tx, physical chunk) fetches the logical chunk that belongs
+// there, and padded slots use an out-of-range offset (the buffer unit writes zeros).  The DMA is issued from inline asm:
+// hipcc makes every compiler-visible LDS read wait for ALL outstanding LDS-DMA (vmcnt(0)), which would serialise the pipeline;
+// the waits are placed by hand (s_waitcnt vmcnt(3): only this wave's newest output stores may still be in flight).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void win_dma16(unsigned lds_wave_base, unsigned voff, i32x4_t rsrc) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave_base), "v"(voff), "s"(rsrc)
+                 : "memory");
+}
+
+template <int WS, int P, int LOG2P>
+__global__ __launch_bounds__(256, 2) void window_attn_pipe_kernel(WinArgs a) {
+    using Cfg = WinCfg<WS, P, LOG2P, 4>;
+    constexpr int RP = Cfg::RP, NQT = Cfg::NQT, QPW = Cfg::QPW;
+    constexpr int KV_BYTES = 2 * RP * Cfg::ROWB;                 // K image then V image
+    constexpr int NDMA = 2 * (RP / 16);                          // wave instructions per item (16 rows each): 28
+    constexpr int DPW = NDMA / 4;                                // per wave: 7
+    static_assert(NDMA % 4 == 0 && P == 16, "one token row per DMA instruction");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tb = reinterpret_cast<float*>(smem + 2 * KV_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    int lb = blockIdx.x;
+    const int nblk = gridDim.x;
+    {   // XCD-aware order: consecutive logical blocks = the heads of one window (neighbouring 64-byte slices of the same lines)
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = lb & 7, idx = lb >> 3;
+        lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int head = lb % a.heads;                               // the same for every item of this block (nblk % heads == 0)
+    const int ldq = a.nq * a.C;
+
+    // descriptor over the whole qkv tensor (wave-uniform words, built from kernel arguments only)
+    const unsigned long qp = (unsigned long)a.qkv;
+    const i32x4_t rq = {(int)(unsigned)qp, (int)((qp >> 32) & 0xffffu), (int)(unsigned)(2L * a.B * a.Hp * a.Wp * ldq), 0x00020000};
+
+    // this lane's part of the DMA plan: instruction j = wave + 4 i  ->  (array = j / 14, token row ty = j % 14), lane = (tx, chunk)
+    unsigned rel[DPW];
+    unsigned dlds[DPW];
+    {
+        const int tx = lane >> 2, pc = lane & 3;
+#pragma unroll
+        for (int i = 0; i < DPW; ++i) {
+            const int j = wave + 4 * i;
+            const int arr = j / (RP / 16), ty = j - arr * (RP / 16);
+            const int row = ty * 16 + tx;
+            const int ch = arr == 0 ? k_slot(row, pc) : (pc ^ (((row >> 2) & 1) << 1));     // both swizzles are involutions
+            const bool valid = (tx < WS) & (ty < WS);
+            rel[i] = valid ? (unsigned)(((ty * a.Wp + tx) * ldq + (a.nq - 2 + arr) * a.C + head * 32 + ch * 8) * 2) : OOB;
+            dlds[i] = (unsigned)(arr * RP * Cfg::ROWB + ty * 1024);
+        }
+    }
+    const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
+
+    struct Item { int b, wy, wx; long img_pix; };
+    auto decode = [&](int item) {
+        Item it;
+        int wq = item / a.heads;
+        it.wx = wq % a.nWx;
+        wq /= a.nWx;
+        it.wy = wq % a.nWy;
+        it.b = wq / a.nWy;
+        it.img_pix = (long)it.b * a.Hp * a.Wp;
+        return it;
+    };
+    auto issue_dma = [&](const Item& it, int buf) {
+        const unsigned base = (unsigned)(((it.img_pix + (long)(it.wy * WS) * a.Wp + it.wx * WS) * ldq) * 2);
+#pragma unroll
+        for (int i = 0; i < DPW; ++i)
+            win_dma16(lds0 + (unsigned)(buf * KV_BYTES) + dlds[i], rel[i] == OOB ? OOB : base + rel[i], rq);
+    };
+    // Q fragments go global -> VGPR through asm loads: a load hipcc can see would make it place its own s_waitcnt in front of
+    // the first use, and - blind to the asm DMA issued in between - that wait would drain the next item's DMA as well.  Masked
+    // lanes use an out-of-range offset (the buffer unit returns zeros).  Destinations are named in the wait statements below.
+    const unsigned long gp = (unsigned long)(a.nq == 2 ? a.qg : a.qkv);
+    const unsigned gbytes = (unsigned)(a.nq == 2 ? 2L * a.B * WS * WS * a.C : 2L * a.B * a.Hp * a.Wp * ldq);
+    const i32x4_t rqq = {(int)(unsigned)gp, (int)((gp >> 32) & 0xffffu), (int)gbytes, 0x00020000};
+    auto load_q = [&](const Item& it, f16x8 (&q)[QPW]) {
+#pragma unroll
+        for (int i = 0; i < QPW; ++i) {
+            const int qn = (wave + i * 4) * 16 + l15;            // dense token index ty*WS + tx
+            const int qy = qn / WS, qx = qn - qy * WS;
+            const long pix = it.img_pix + (long)(it.wy * WS + qy) * a.Wp + (it.wx * WS + qx);
+            const long e = (a.nq == 2) ? ((long)it.b * WS * WS + qy * WS + qx) * a.C + head * 32 + g * 8 : pix * ldq + head * 32 + g * 8;
+            const unsigned off = qn < WS * WS ? (unsigned)(e * 2) : OOB;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(q[i]) : "v"(off), "s"(rqq) : "memory");
+        }
+    };
+
+    int item = lb;                                               // block-uniform; nblk <= items, so the first item exists
+    Item cur = decode(item);
+    static_assert(QPW == 4, "the wait statements name four Q fragments");
+    f16x8 qf[QPW], qn[QPW];
+    issue_dma(cur, 0);
+    load_q(cur, qf);
+    {   // the head's bias table, once per workgroup (same image as in the kernel above)
+        constexpr int TIT = (Cfg::TB_FLOATS + 255) / 256;
+        float tv[TIT];
+#pragma unroll
+        for (int it = 0; it < TIT; ++it) {
+            const int i = tid + it * 256;
+            const int e = i - Cfg::TOFF;
+            const int ry = e / Cfg::TW, rx = e - ry * Cfg::TW;
+            const bool in_tab = (i >= Cfg::TOFF) & (i < Cfg::TB_FLOATS) & (rx < Cfg::TROWS);
+            const int gi = in_tab ? (ry * Cfg::TROWS + rx) * a.heads + head : 0;
+            const float t = a.table[gi];
+            tv[it] = in_tab ? t * a.inv_scale : (i < Cfg::TOFF ? -1.0e30f : 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < TIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < Cfg::TB_FLOATS) tb[i] = tv[it];
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
+    __builtin_amdgcn_s_barrier();
+
+    int buf = 0;
+    while (true) {
+        const int nxt_item = item + nblk;
+        const bool has_next = nxt_item < a.items;                // block-uniform
+        Item nxt = cur;
+        if (has_next) {
+            nxt = decode(nxt_item);
+            issue_dma(nxt, buf ^ 1);                             // the other buffer was last read before the previous barrier
+            load_q(nxt, qn);
+        }
+        const char* k_lds = smem + buf * KV_BYTES;
+        const char* v_lds = k_lds + RP * Cfg::ROWB;
+#pragma unroll
+        for (int i = 0; i < QPW; ++i) {
+            const int qt = wave + i * 4;
+            if (qt >= NQT) break;  // wave-uniform
+            U4H8 qv;
+            qv.h = qf[i];
+            win_query_tile<WS, P, LOG2P, 4>(a, qv, k_lds, v_lds, tb, qt, l15, g, true, cur.img_pix, cur.wy, cur.wx, head);
+        }
+        if (!has_next) break;
+        // everything older than this wave's (at most QPW) newest output stores has retired: the DMA and Q loads of the next item
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3])::"memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < QPW; ++i) qf[i] = qn[i];
+        item = nxt_item;
+        cur = nxt;
+        buf ^= 1;
+    }
+}
+
+template <int WS, int P, int LOG2P>
+int launch_win_pipe(const WinArgs& a, hipStream_t s) {
+    using Cfg = WinCfg<WS, P, LOG2P, 4>;
+    constexpr int SMEM = 2 * 2 * Cfg::RP * Cfg::ROWB + (Cfg::TB_FLOATS * 4 + 15) / 16 * 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_pipe_kernel<WS, P, LOG2P>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        attr_set = true;
+    }
+    int wgs = 512;                                              // two 66 KB workgroups per CU
+    if (wgs > a.items) wgs = a.items;
+    wgs -= wgs % a.heads;                                       // a workgroup keeps one head: items b, b + wgs, ... share it
+    hipLaunchKernelGGL((window_attn_pipe_kernel<WS, P, LOG2P>), dim3(wgs), dim3(256), SMEM, s, a);
+    return vip_launch_status("vip_window_attn_fwd_f16(pipe)");
+}
+
+template <int WS, int P, int LOG2P, int WPI>
 int launch_win(const WinArgs& a, hipStream_t s) {
     using Cfg = WinCfg<WS, P, LOG2P, WPI>;
     static bool attr_set = false;
@@ -354,5 +543,9 @@ extern "C" int vip_window_attn_fwd_f16(const void* qkv, const void* q_global, co
     a.scale_log2e = scale * 1.44269504088896f;
     a.inv_scale = 1.f / scale;
     if (ws == 7) return launch_win<7, 8, 3, 1>(a, (hipStream_t)stream);
+    // ws 14: the pipelined persistent kernel once every workgroup gets at least two items (VIP_ATTN_PIPE=0: never)
+    static const int pipe = getenv("VIP_ATTN_PIPE") ? atoi(getenv("VIP_ATTN_PIPE")) : 1;
+    if (pipe && items >= 1024 && items % heads == 0 && 2L * B * Hp * Wp * nq * C < 0x7FFF0000L)
+        return launch_win_pipe<14, 16, 4>(a, (hipStream_t)stream);
     return launch_win<14, 16, 4, 4>(a, (hipStream_t)stream);
 }
