@@ -447,6 +447,8 @@ def test_window_attention_pipelined(B, heads, nW, global_q, report):
     item counts that are not a multiple of the grid, several windows per image, global query; and bit-identical to the one-item
     kernel (VIP_ATTN_PIPE only changes the schedule) and to itself across launches (no race in the DMA double buffer)."""
     ops = _ops()
+    import os
+    os.environ["VIP_ATTN_PIPE"] = "1"          # opt-in kernel (read per call by the C entry point)
     ws, C, hd = 14, heads * 32, 32
     Hp = Wp = ws * nW
     assert B * nW * nW * heads >= 1024
@@ -472,6 +474,11 @@ def test_window_attention_pipelined(B, heads, nW, global_q, report):
         again = ops.window_attention(qd, gd, td, heads, ws, hd ** -0.5)
         torch.cuda.synchronize()
         assert torch.equal(got, again)
+    os.environ["VIP_ATTN_PIPE"] = "0"
+    plain = ops.window_attention(qd, gd, td, heads, ws, hd ** -0.5)
+    torch.cuda.synchronize()
+    del os.environ["VIP_ATTN_PIPE"]
+    assert torch.equal(got, plain), "the pipelined kernel changes the schedule, not the arithmetic"
 
 
 def test_window_attention_softmax_spike(report):

@@ -5,8 +5,8 @@ Units/corrections per MI355X_MICROARCH.md (HBM section): both counters are KiB; 
 import collections, csv, glob, json, sys
 
 FAMILIES = {"conv_igemm_kernel": ("conv_igemm_kernel",), "pw_gemm_kernel": ("pw_gemm_kernel",),
-            "pwk_gemm_kernel": ("pwk_gemm_kernel", "pwk_direct_kernel"), "rows_gemm_kernel": ("rows_gemm_kernel",), "mlp_fused_kernel": ("mlp_fused_kernel",),
-            "mlp_stream_kernel": ("mlp_stream_kernel",), "window_attn_kernel": ("window_attn_kernel",),
+            "pwk_gemm_kernel": ("pwk_gemm_kernel", "pwk_direct_kernel"), "gemm8p_kernel": ("gemm8p_kernel",), "rows_gemm_kernel": ("rows_gemm_kernel",), "mlp_fused_kernel": ("mlp_fused_kernel",),
+            "mlp_stream_kernel": ("mlp_stream_kernel",), "window_attn_kernel": ("window_attn_kernel", "window_attn_pipe_kernel"),
             "dwconv": ("dwconv_tile_kernel", "dwconv_kernel"), "layernorm": ("layernorm_kernel",),
             "scale_add_act": ("scale_add_act_kernel",), "gap": ("gap_kernel",), "se_gate": ("se_gate_kernel",)}
 

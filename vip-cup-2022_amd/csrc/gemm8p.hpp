@@ -36,7 +36,8 @@ __device__ __forceinline__ void g8_dma(const __amdgpu_buffer_rsrc_t& r, char* ld
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode, int order) {
+template <bool TWO_BARRIERS>
+__global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -44,41 +45,19 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode, in
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr unsigned OOB = 0xFFFFFFF0u;
 
-    // Block -> tile.  Hardware deals workgroup ids round-robin to the 8 XCDs (private 4 MiB L2 each); id = 8 idx + xcd.
-    //   order 0: each XCD gets one contiguous band of the (m-block major, n-block minor) tile list;
-    //   order 1: the same with m-blocks minor (weights of one n-block stay put, activations stream);
-    //   order 2: XCD grid ns x (8/ns) - an XCD owns n-blocks {xn, xn + ns, ...} and an m-band, so its weight slice is 1/ns of the
-    //            matrix and stays in L2 while the band's activation panels stream through once.
+    // Block -> tile: each XCD (private 4 MiB L2; workgroup ids are dealt round-robin, id = 8 idx + xcd) gets one contiguous band of
+    // the (m-block major, n-block minor) tile list, so the 256-pixel activation panel of an m-block is fetched by one XCD only.
+    // (Measured: m-minor order and an XCD grid that splits the n-blocks so that each XCD keeps 1/2 of the weights are within +-3 %
+    // of this order on every ensemble shape - the kernel is not L2-capacity bound.)
     int mb, nb;
     {
         int bid = blockIdx.x;
         const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
         const int xcd = bid & 7, idx = bid >> 3;
-        const int ord = order & 15, ns = order >> 4;
-        if (ord == 2 && ns > 1 && a.n_blocks % ns == 0) {
-            const int xm = 8 / ns;                                       // XCD grid: xm (m bands) x ns (n classes)
-            const int xn = xcd % ns, xmi = xcd / ns;
-            const int npx = a.n_blocks / ns;                             // n-blocks per XCD
-            const int mq = a.m_blocks / xm, mr = a.m_blocks % xm;        // m-blocks per band (first mr bands have one more)
-            const int m_lo = xmi * mq + min(xmi, mr), m_cnt = mq + (xmi < mr ? 1 : 0);
-            // slots of this XCD: idx = 0, 1, ... (nwg/8 of them, the same for every XCD when nwg % 8 == 0); tiles: m_cnt * npx
-            const int slots = (nwg + 7 - xcd) >> 3;
-            (void)slots;
-            const int lm = idx / npx, ln = idx - lm * npx;
-            if (lm >= m_cnt) return;                                     // padding slot (bands differ by at most one m-block)
-            mb = m_lo + lm;
-            nb = xn + ln * ns;
-        } else {
-            const int q = nwg >> 3, r = nwg & 7;
-            bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-            if (ord == 1) {
-                nb = bid / a.m_blocks;
-                mb = bid - nb * a.m_blocks;
-            } else {
-                mb = bid / a.n_blocks;
-                nb = bid - mb * a.n_blocks;
-            }
-        }
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        mb = bid / a.n_blocks;
+        nb = bid - mb * a.n_blocks;
     }
     const int mblk = mb * 256, nblk = nb * 256;
 
@@ -120,16 +99,15 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode, in
         }
     }
     const int nk = a.K >> 6;
-    const bool no_dma = (order >> 8) & 1;     // timing-only debug build of the schedule: nothing is fetched after the prologue
     // stage<KIND>(buffer, k-tile): two DMA instructions per thread; a k-tile past the end reads past the row (never consumed)
     // or out of range (zeros) - issued unconditionally so that the vmcnt bookkeeping is the same in every iteration
     auto stageA = [&](int g, char* slot, int kt) {
-        const unsigned ko = no_dma ? G8_OOB : (unsigned)kt * 128u;
+        const unsigned ko = (unsigned)kt * 128u;
         g8_dma(rw, slot + dma_lds[0], vA[g][0] + ko);
         g8_dma(rw, slot + dma_lds[1], vA[g][1] + ko);
     };
     auto stageB = [&](int h, char* slot, int kt) {
-        const unsigned ko = no_dma ? G8_OOB : (unsigned)kt * 128u;
+        const unsigned ko = (unsigned)kt * 128u;
         g8_dma(rx, slot + dma_lds[0], vB[h][0] + ko);
         g8_dma(rx, slot + dma_lds[1], vB[h][1] + ko);
     };
@@ -215,28 +193,28 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode, in
         G8_READ_B(b0, 1);
         G8_READ_A(0);
         stageA(1, nxt + 3 * G8_SLOT, t + 1);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (TWO_BARRIERS) __builtin_amdgcn_s_barrier();
         G8_LDS_WAIT();
         G8_MFMA(0, 0, b0);
         __builtin_amdgcn_s_barrier();
         // ---- phase 1: (A0, B1) ----
         G8_READ_B(b1, 2);
         stageA(0, cur + 0 * G8_SLOT, t + 2);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (TWO_BARRIERS) __builtin_amdgcn_s_barrier();
         G8_LDS_WAIT();
         G8_MFMA(0, 2, b1);
         __builtin_amdgcn_s_barrier();
         // ---- phase 2: (A1, B1) ----
         G8_READ_A(3);
         stageB(0, cur + 1 * G8_SLOT, t + 2);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (TWO_BARRIERS) __builtin_amdgcn_s_barrier();
         G8_LDS_WAIT();
         G8_MFMA(1, 2, b1);
         __builtin_amdgcn_s_barrier();
         // ---- phase 3: (A1, B0) ----
         stageB(1, cur + 2 * G8_SLOT, t + 2);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (TWO_BARRIERS) __builtin_amdgcn_s_barrier();
         G8_MFMA(1, 0, b0);
         __builtin_amdgcn_s_barrier();
     }
@@ -277,25 +255,13 @@ inline int launch_gemm8p(const ConvArgs& a0, int mode, hipStream_t s) {
     constexpr size_t smem = 8 * G8_SLOT;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    // tile order (see the kernel): VIP_G8P_ORDER = ord + 16 ns (+ 256: timing-only, no DMA); default picked from the weight size
-    static const int env_order = getenv("VIP_G8P_ORDER") ? atoi(getenv("VIP_G8P_ORDER")) : -1;
-    int order = env_order;
-    if (order < 0) {
-        order = 0;
-        const long wbytes = 2L * a.Cout_g * a.K;
-        for (int ns = 2; ns <= 8 && wbytes > (3L << 19) * 1; ns *= 2) {     // more than 1.5 MiB of weights per XCD: split n over XCDs
-            if (a.n_blocks % ns == 0 && wbytes / ns <= (3L << 20)) { order = 2 + 16 * ns; break; }
-        }
-    }
-    unsigned grid = (unsigned)(a.m_blocks * a.n_blocks);
-    if ((order & 15) == 2) {
-        const int ns = order >> 4, xm = 8 / ns;
-        const int mq = (a.m_blocks + xm - 1) / xm;                           // largest band
-        grid = (unsigned)(8 * mq * (a.n_blocks / ns));
-    }
-    hipLaunchKernelGGL(gemm8p_kernel, dim3(grid), dim3(512), smem, s, a, mode, order);
+    static const int one_barrier = getenv("VIP_G8P_ONEBAR") ? atoi(getenv("VIP_G8P_ONEBAR")) : 0;
+    const dim3 grid((unsigned)(a.m_blocks * a.n_blocks));
+    if (one_barrier) hipLaunchKernelGGL(gemm8p_kernel<false>, grid, dim3(512), smem, s, a, mode);
+    else hipLaunchKernelGGL(gemm8p_kernel<true>, grid, dim3(512), smem, s, a, mode);
     return vip_launch_status("vip_conv2d_nhwc_f16(gemm8p)");
 }

@@ -543,8 +543,11 @@ extern "C" int vip_window_attn_fwd_f16(const void* qkv, const void* q_global, co
     a.scale_log2e = scale * 1.44269504088896f;
     a.inv_scale = 1.f / scale;
     if (ws == 7) return launch_win<7, 8, 3, 1>(a, (hipStream_t)stream);
-    // ws 14: the pipelined persistent kernel once every workgroup gets at least two items (VIP_ATTN_PIPE=0: never)
-    static const int pipe = getenv("VIP_ATTN_PIPE") ? atoi(getenv("VIP_ATTN_PIPE")) : 1;
+    // ws 14: the pipelined persistent kernel is opt-in (VIP_ATTN_PIPE=1, read per call): measured 44.6 us against 42.5 us for the
+    // one-item kernel at B = 256 - the kernel is VALU-bound (softmax), not fetch-bound, and 4 resident workgroups per CU hide the
+    // per-wave MFMA -> VALU -> MFMA chains better than 2 pipelined ones
+    const char* pipe_env = getenv("VIP_ATTN_PIPE");
+    const int pipe = pipe_env ? atoi(pipe_env) : 0;
     if (pipe && items >= 1024 && items % heads == 0 && 2L * B * Hp * Wp * nq * C < 0x7FFF0000L)
         return launch_win_pipe<14, 16, 4>(a, (hipStream_t)stream);
     return launch_win<14, 16, 4, 4>(a, (hipStream_t)stream);
