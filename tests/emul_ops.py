@@ -115,7 +115,9 @@ def layernorm(x, gamma, beta, eps):
 POOL_MAX_ZEROPAD, POOL_AVG_VALID, POOL_AVG_FULL = 0, 1, 2
 
 
-def pool2d(x, k, stride, pad=(0, 0, 0, 0), mode=0):
+def pool2d(x, k, stride, pad=(0, 0, 0, 0), mode=0, out_hw=None):
+    if out_hw is not None:
+        return pool2d(x, k, stride, pad, mode)[:, :out_hw[0], :out_hw[1], :].contiguous()
     if mode == 0:
         return _r(R.maxpool_valid(x, k, stride, pad), "pool")
     if mode == 2:

@@ -123,6 +123,27 @@ def test_kecam_legacy_configs_reduced_depth(report):
         del km.EFFNET[name], ref.EFFNET[name]
 
 
+def test_efficientnet_v2l_full_depth(report):
+    """EfficientNetV2L (efficientnet_v2.py:313-325; a member of the earlier ensembles, main.py:43-56) at FULL depth (79 blocks), 2 images:
+    the seeded weights keep its activations inside fp16 range (oracle max 6.2e3), so the whole graph can be held to the oracle."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ops, zoo
+    spec = zoo.MEMBERS["efficientnet_v2l"]
+    p = spec.synth(spec.seed)
+    x = _images(2, 200).to(torch.float16).to(torch.float32)
+    ca, cb = [], []
+    with torch.no_grad():
+        z_ref = ref.predict_logits("EfficientNetV2L", p, x)
+        ref.features("EfficientNetV2L", p, x, collect=ca)
+    m = spec.ctor(p)
+    xd = ops.to_device_nhwc8(x)
+    m.features(xd, collect=cb)
+    z = m.logits(xd).cpu()
+    torch.cuda.synchronize()
+    assert torch.isfinite(z).all()
+    _compare(report, "EfficientNetV2L full", ca, cb, z, z_ref)
+
+
 def test_hornet_reduced_depth(report):
     """HorNetBase (hornet.py:196-198) at depths (1,1,2,1): recursive gated convolution with 2..5 orders, depthwise 7x7 on
     the 2C - C/2^(n-1) gate channels, channel-slice products, folded layer scales, LN -> Dense head."""

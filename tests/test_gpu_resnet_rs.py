@@ -57,6 +57,15 @@ def test_resnet_rs101_full(report):
     assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())
 
 
+def test_resnet_rs200_full(report):
+    """ResNet-RS-200 (block_args.py: 3, 24, 36, 3 bottlenecks), a member of the earlier ensembles (main.py:43-56): 2 images, full depth."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import resnet_rs
+    fe, frms, ze, z_ref = _run(resnet_rs.BLOCK_ARGS[200], 200, 2, report, "rs200", 1026)
+    assert frms < 6e-3
+    assert ze < 4e-3 * max(1.0, z_ref.abs().max().item())
+
+
 def test_resnet_rs50_full(report):
     """Full ResNet-RS-50 at 200x200 on 8 synthetic images: logits vs the fp32 oracle."""
     fe, frms, ze, z_ref = _run(None, 200, 8, report, "rs50", 1006)

@@ -49,13 +49,13 @@ def _model_check(report, tag, z, z_ref, ca, cb):
     return ze
 
 
-@pytest.mark.parametrize("name", ["vit_tiny_patch16_224", "vit_small_patch16_224"])
+@pytest.mark.parametrize("name", ["vit_tiny_patch16_224", "vit_small_patch16_224", "vit_base_patch16_224"])
 def test_vit(name, report):
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops, tfimm_models as tm
     cfg = tm.VIT_CONFIGS[name]
     p = tm.vit_synth_params(cfg, seed=1010)
-    x = _images(4, 224).to(torch.float16).to(torch.float32)
+    x = _images(2 if "base" in name else 4, 224).to(torch.float16).to(torch.float32)
     ca, cb = [], []
     with torch.no_grad():
         ref.vit_forward_tokens(p, x, name, collect=ca)
@@ -69,7 +69,7 @@ def test_vit(name, report):
     assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["convnext_tiny_in22k", "convnext_small_in22k", "convnext_base_in22k"])
+@pytest.mark.parametrize("name", ["convnext_tiny_in22k", "convnext_small_in22k", "convnext_base_in22k", "convnext_large_in22ft1k"])
 def test_convnext(name, report):
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops, tfimm_models as tm

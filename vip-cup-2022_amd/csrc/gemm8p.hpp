@@ -36,7 +36,7 @@ __device__ __forceinline__ void g8_dma(const __amdgpu_buffer_rsrc_t& r, char* ld
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
-template <bool TWO_BARRIERS>
+template <bool TWO_BARRIERS, bool PIPE>
 __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,13 +142,14 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
     stageA(0, g8_slot<0>(smem, 1), 1);
     stageB(0, g8_slot<1>(smem, 1), 1);
     stageB(1, g8_slot<2>(smem, 1), 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (PIPE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // A0, B0, B1 of tile 0 have landed
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                    // all of tile 0
     __builtin_amdgcn_s_barrier();
 
     // Fragment reads are inline-asm ds_read_b128: hipcc's waitcnt pass makes every compiler-visible LDS read wait for ALL
     // outstanding LDS-DMA (vmcnt(0) in front of each read group - it cannot tell which slot a read touches), which would drain
     // the ring four times per k-tile.  The asm reads are ordered by hand: s_waitcnt lgkmcnt(0) + sched_barrier before the MFMAs.
-    U4H8 af[4][2], b0[2][2], b1[2][2];                     // [tile][k-step]
+    U4H8 af[4][2], af2[PIPE ? 4 : 1][2], b0[2][2], b1[2][2];   // [tile][k-step]; af2: the second weight-fragment set of the pipelined schedule
     const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)smem;
     const unsigned a_base0 = lds0 + (unsigned)(a_off + fo0), a_base1 = lds0 + (unsigned)(a_off + fo1);
     const unsigned b_base0 = lds0 + (unsigned)(b_off + fo0), b_base1 = lds0 + (unsigned)(b_off + fo1);
@@ -172,17 +173,101 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
         __builtin_amdgcn_sched_barrier(0);                    \
     } while (0)
-#define G8_MFMA(G, P0, BF)                                                                                              \
+#define G8_MFMA2(G, P0, AF, BF)                                                                                              \
     do {                                                                                                                \
         __builtin_amdgcn_s_setprio(1);                                                                                  \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                            \
                 _Pragma("unroll") for (int pp = 0; pp < 2; ++pp)                                                        \
-                    acc[G][P0 + pp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt][ks].h, BF[pp][ks].h,            \
+                    acc[G][P0 + pp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[nt][ks].h, BF[pp][ks].h,            \
                                                                                  acc[G][P0 + pp][nt], 0, 0, 0);        \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
     } while (0)
 
+#define G8_MFMA(G, P0, BF) G8_MFMA2(G, P0, af, BF)
+    if constexpr (PIPE) {
+        // ---- software-pipelined schedule: the fragments phase p+1 needs are read (into registers no MFMA of phase p touches)
+        // BEFORE phase p's MFMAs, so the LDS pipe works under the matrix pipe instead of between its bursts.  Register roles per
+        // k-tile: A0 -> af, A1 -> af2, B0 -> BP, B1 -> BQ with BP / BQ swapping every tile (the B0 of tile t+1 is read into the set
+        // that held B1 of tile t).  Reads: p0 B1(t), p1 A1(t), p2 A0(t+1), p3 B0(t+1); DMA as before (p0 A1(t+1), p1 A0(t+2), p2
+        // B0(t+2), p3 B1(t+2)) but with s_waitcnt vmcnt(8) in EVERY phase: four half-tiles stay in flight and each one is read five
+        // phases after it was issued, one barrier after the wait that retired it.  A slot is rewritten three phases after its
+        // last read.  The wait for a phase's reads sits at the END of the phase and names their destinations, so no asm load is in
+        // flight across the loop's back edge (hipcc may copy loop-carried registers there).
+#define G8_RA(AF, BASE0, BASE1, KIND)                                                            \
+    do {                                                                                         \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                       \
+            G8_DSR(AF[nt][0].h, BASE0, (KIND) * G8_SLOT + nt * 2048);                            \
+            G8_DSR(AF[nt][1].h, BASE1, (KIND) * G8_SLOT + nt * 2048);                            \
+        }                                                                                        \
+    } while (0)
+#define G8_RB(BF, BASE0, BASE1, KIND)                                                            \
+    do {                                                                                         \
+        _Pragma("unroll") for (int pp = 0; pp < 2; ++pp) {                                       \
+            G8_DSR(BF[pp][0].h, BASE0, (KIND) * G8_SLOT + pp * 2048);                            \
+            G8_DSR(BF[pp][1].h, BASE1, (KIND) * G8_SLOT + pp * 2048);                            \
+        }                                                                                        \
+    } while (0)
+#define G8_WAIT_A(AF)                                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                     \
+                 : "+v"(AF[0][0].h), "+v"(AF[0][1].h), "+v"(AF[1][0].h), "+v"(AF[1][1].h), "+v"(AF[2][0].h), "+v"(AF[2][1].h), \
+                   "+v"(AF[3][0].h), "+v"(AF[3][1].h)::"memory")
+#define G8_WAIT_B(BF) \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(BF[0][0].h), "+v"(BF[0][1].h), "+v"(BF[1][0].h), "+v"(BF[1][1].h)::"memory")
+#define G8_PHASE_MID()                                    \
+    do {                                                  \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+#define G8_TILE(B, BP, BQ, TT)                                                                         \
+    do {                                                                                               \
+        char* cur = smem + (B) * 4 * G8_SLOT;                                                          \
+        char* nxt = smem + ((B) ^ 1) * 4 * G8_SLOT;                                                    \
+        const unsigned co = (unsigned)((B) * 4 * G8_SLOT), no = (unsigned)(((B) ^ 1) * 4 * G8_SLOT);   \
+        /* p0: (A0, B0) */                                                                             \
+        G8_RB(BQ, b_base0 + co, b_base1 + co, 2);                                                      \
+        stageA(1, nxt + 3 * G8_SLOT, (TT) + 1);                                                        \
+        G8_PHASE_MID();                                                                                \
+        G8_MFMA2(0, 0, af, BP);                                                                        \
+        G8_WAIT_B(BQ);                                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        /* p1: (A0, B1) */                                                                             \
+        G8_RA(af2, a_base0 + co, a_base1 + co, 3);                                                     \
+        stageA(0, cur + 0 * G8_SLOT, (TT) + 2);                                                        \
+        G8_PHASE_MID();                                                                                \
+        G8_MFMA2(0, 2, af, BQ);                                                                        \
+        G8_WAIT_A(af2);                                                                                \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        /* p2: (A1, B1) */                                                                             \
+        G8_RA(af, a_base0 + no, a_base1 + no, 0);                                                      \
+        stageB(0, cur + 1 * G8_SLOT, (TT) + 2);                                                        \
+        G8_PHASE_MID();                                                                                \
+        G8_MFMA2(1, 2, af2, BQ);                                                                       \
+        G8_WAIT_A(af);                                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                  \
+        /* p3: (A1, B0) */                                                                             \
+        G8_RB(BQ, b_base0 + no, b_base1 + no, 1);                                                      \
+        stageB(1, cur + 2 * G8_SLOT, (TT) + 2);                                                        \
+        G8_PHASE_MID();                                                                                \
+        G8_MFMA2(1, 0, af2, BP);                                                                       \
+        G8_WAIT_B(BQ);                                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                  \
+    } while (0)
+        G8_RA(af, a_base0, a_base1, 0);
+        G8_RB(b0, b_base0, b_base1, 1);
+        G8_WAIT_A(af);
+        G8_WAIT_B(b0);
+        for (int t = 0; t < nk; t += 2) {          // nk is even (K % 128 == 0)
+            G8_TILE(0, b0, b1, t);
+            G8_TILE(1, b1, b0, t + 1);
+        }
+#undef G8_TILE
+#undef G8_PHASE_MID
+#undef G8_WAIT_A
+#undef G8_WAIT_B
+#undef G8_RA
+#undef G8_RB
+    } else
     for (int t = 0; t < nk; ++t) {
         const int b = t & 1;
         char* cur = smem + b * 4 * G8_SLOT;
@@ -223,6 +308,7 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
 #undef G8_READ_B
 #undef G8_LDS_WAIT
 #undef G8_MFMA
+#undef G8_MFMA2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the ring's last (unused) half-tiles: nothing may land after the workgroup ends
 
     int m_base = mblk + wm * 64 + l15, n_lane = nblk + wn * 128 + lq * 8;
@@ -255,13 +341,16 @@ inline int launch_gemm8p(const ConvArgs& a0, int mode, hipStream_t s) {
     constexpr size_t smem = 8 * G8_SLOT;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8p_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         attr_set = true;
     }
-    static const int one_barrier = getenv("VIP_G8P_ONEBAR") ? atoi(getenv("VIP_G8P_ONEBAR")) : 0;
+    // VIP_G8P_VARIANT: 2 = software-pipelined fragment reads (default where K % 128 == 0), 1 = one barrier per phase, 0 = two
+    static const int variant = getenv("VIP_G8P_VARIANT") ? atoi(getenv("VIP_G8P_VARIANT")) : 2;
     const dim3 grid((unsigned)(a.m_blocks * a.n_blocks));
-    if (one_barrier) hipLaunchKernelGGL(gemm8p_kernel<false>, grid, dim3(512), smem, s, a, mode);
-    else hipLaunchKernelGGL(gemm8p_kernel<true>, grid, dim3(512), smem, s, a, mode);
+    if (variant == 2 && a.K % 128 == 0) hipLaunchKernelGGL((gemm8p_kernel<false, true>), grid, dim3(512), smem, s, a, mode);
+    else if (variant >= 1) hipLaunchKernelGGL((gemm8p_kernel<false, false>), grid, dim3(512), smem, s, a, mode);
+    else hipLaunchKernelGGL((gemm8p_kernel<true, false>), grid, dim3(512), smem, s, a, mode);
     return vip_launch_status("vip_conv2d_nhwc_f16(gemm8p)");
 }

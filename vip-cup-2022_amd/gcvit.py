@@ -174,9 +174,9 @@ class GCViT:
         B, H, W, C = x.shape
         ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
         if ph or pw:
-            # FitWindow (feature.py:240-249): zero-pad BOTH sides to a multiple of the window, the odd pixel after.
-            # NHWC: F.pad pairs run from the last axis backwards -> (C, C, W-left, W-right, H-top, H-bottom).
-            x = torch.nn.functional.pad(x, (0, 0, pw // 2, pw // 2 + pw % 2, ph // 2, ph // 2 + ph % 2)).contiguous()
+            # FitWindow (feature.py:240-249): zero-pad BOTH sides to a multiple of the window, the odd pixel after - a 1 x 1
+            # zero-pad "pooling" launch (vip_pool2d_nhwc_f16 with k = 1 copies in-range pixels and writes 0 elsewhere)
+            x = ops.pool2d(x, 1, 1, (ph // 2, ph // 2 + ph % 2, pw // 2, pw // 2 + pw % 2), ops.POOL_MAX_ZEROPAD)
         qg = x
         for branch, keep_dim in lv["qgen"]:
             qg = branch(qg)
@@ -186,7 +186,7 @@ class GCViT:
         for blk in lv["blocks"]:
             x = blk(x, qg)
         if ph or pw:
-            x = x[:, :H, :W, :].contiguous()      # level.py:61 crops from the top-left corner (sic), as the reference does
+            x = ops.pool2d(x, 1, 1, (0, 0, 0, 0), ops.POOL_MAX_ZEROPAD, out_hw=(H, W))   # level.py:61 crops from the top-left corner (sic), as the reference does
         if lv["down"] is not None:
             x = lv["down"](x)
         return x

@@ -380,12 +380,17 @@ def layernorm(x, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
 POOL_MAX_ZEROPAD, POOL_AVG_VALID, POOL_AVG_FULL = 0, 1, 2
 
 
-def pool2d(x, k: int, stride: int, pad=(0, 0, 0, 0), mode=POOL_MAX_ZEROPAD):
+def pool2d(x, k: int, stride: int, pad=(0, 0, 0, 0), mode=POOL_MAX_ZEROPAD, out_hw=None):
+    """``out_hw`` = (Ho, Wo) asks for fewer output rows / columns than the padding implies (a top-left crop); with k = 1,
+    stride 1 and zero-pad max pooling the op is a zero-padded copy (GCViT FitWindow) or a crop (level.py:61)."""
     _chk16(x, "pool2d.x")
     B, H, W, Cc = x.shape
     pt, pb, pl, pr = pad
     Ho = (H + pt + pb - k) // stride + 1
     Wo = (W + pl + pr - k) // stride + 1
+    if out_hw is not None:
+        assert out_hw[0] <= Ho and out_hw[1] <= Wo
+        Ho, Wo = out_hw
     out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float16, device=x.device)
     st = _abi.lib().vip_pool2d_nhwc_f16(_p(x), _p(out), B, H, W, Cc, Cc, Cc, k, stride, pt, pl, Ho, Wo, mode,
                                         _stream())
