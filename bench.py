@@ -61,10 +61,20 @@ def note(msg: str):
 
 
 def host_cores() -> int:
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup CPU quota where one is set, and to the
+    16-core share a one-GPU box of this pool gives its GPU (its affinity mask shows every core of the host; 256 torch threads on
+    a 16-core share make the CPU leg crawl)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return min(n, int(os.environ.get("VIP_CPU_THREADS", "16")))
 
 
 def cpu_baseline(wl, timed_batches: int):

@@ -14,12 +14,13 @@ for M, N, K in SHAPES:
     x = torch.randn((M, K), generator=g, dtype=torch.float16).cuda() if M * K < 3e8 else torch.randn((M, K), dtype=torch.float16, device="cuda")
     cw = ops.make_dense_weight(torch.randn((K, N), generator=g) * 0.05, torch.zeros(N))
     res = torch.zeros((M, N), dtype=torch.float16, device="cuda")
-    y = ops.dense(x, cw, act="gelu")
+    ACT = None if "--noact" in sys.argv else "gelu"
+    y = ops.dense(x, cw, act=ACT)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        ops.dense(x, cw, act="gelu")
+        ops.dense(x, cw, act=ACT)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     print(f"M={M:8d} N={N:5d} K={K:5d} {ms*1e3:8.1f} us {2.0*M*N*K/ms/1e9:7.1f} TF {2.0*(M*K+M*N)/ms/1e6:7.0f} GB/s", flush=True)
