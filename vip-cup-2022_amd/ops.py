@@ -18,7 +18,8 @@ _PROF = None
 
 
 def set_profiler(p):
-    """Install (or clear with None) a per-launch profiler: an object with start(family, flops, bytes) / stop(tok)."""
+    """Install (or clear with None) a per-launch profiler: an object with start(kernel, flops, bytes, tag=None) / stop(tok);
+    ``tag`` describes the launch's shape (GEMM-like operators only)."""
     global _PROF
     _PROF = p
 
@@ -236,7 +237,9 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
         kk = cw.kh * cw.kw * cw.alg_cin_g
         name = conv_kernel_name(d, residual is not None, gate is not None, cw.w_lo is not None) or "unsupported"
         tok = _PROF.start(name, 2.0 * M * cw.cout * kk,
-                          2.0 * (B * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()))
+                          2.0 * (B * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()),
+                          f"M={M} N={cw.cout} K={cw.kh * cw.kw * cw.cin_g} k{cw.kh} s{sh} g{cw.groups}"
+                          f"{' gate' if gate is not None else ''}{' res' if residual is not None else ''} act={act}")
     if cw.w_lo is not None:
         if gate is not None:
             raise _abi.VipError("conv2d: a two-term-weight layer cannot take a gate")
@@ -274,7 +277,8 @@ def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Op
                           act_post=_act(act_post))
         name = conv_kernel_name(d, residual is not None) or "unsupported"
         tok = _PROF.start(name, 2.0 * M * cw.cout * K,
-                          2.0 * (M * K + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()))
+                          2.0 * (M * K + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()),
+                          f"M={M} N={cw.cout} K={K} dense{' res' if residual is not None else ''} act={act}")
     st = _abi.lib().vip_gemm_bias_act_f16(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), M, cw.cout, K,
                                           K, cw.ldw, cw.cout, ldr, _act(act), _act(act_post), _stream())
     if tok is not None:

@@ -32,11 +32,11 @@ class KernelProfile:
     def __init__(self):
         self.rec: List = []
 
-    def start(self, family: str, flops: float, nbytes: float):
+    def start(self, family: str, flops: float, nbytes: float, tag=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        return (family, flops, nbytes, e0, e1)
+        return (family, flops, nbytes, e0, e1, tag)
 
     def stop(self, tok):
         tok[4].record()
@@ -45,13 +45,26 @@ class KernelProfile:
     def summary(self) -> Dict[str, Dict[str, float]]:
         torch.cuda.synchronize()
         out: Dict[str, Dict[str, float]] = {}
-        for fam, fl, nb, e0, e1 in self.rec:
+        for fam, fl, nb, e0, e1, _tag in self.rec:
             d = out.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
             d["bytes"] += nb
         return out
+
+
+    def by_shape(self):
+        """[(kernel, shape tag, launches, ms, flops, bytes)] sorted by time: the per-shape view tools/profile_shapes.py prints"""
+        torch.cuda.synchronize()
+        agg: Dict = {}
+        for fam, fl, nb, e0, e1, tag in self.rec:
+            d = agg.setdefault((fam, tag), [0, 0.0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += fl
+            d[3] += nb
+        return sorted(((k[0], k[1], *v) for k, v in agg.items()), key=lambda r: -r[3])
 
 
 def kernel_family(name: str) -> str:
