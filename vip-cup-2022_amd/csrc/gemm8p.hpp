@@ -109,15 +109,16 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
         }
     };
     const int nk = a.K >> 6;
-    // stage(slot, k-tile): two DMA instructions per thread; a k-tile past the end reads past the row (never consumed) or out of
-    // range (zeros) - issued unconditionally so that the vmcnt bookkeeping is the same in every iteration
+    // stage(slot, k-tile): two DMA instructions per thread.  The ring runs two k-tiles past the end of K; those stages are issued
+    // all the same (the vmcnt bookkeeping is identical in every iteration) but with an out-of-range offset: zeros, no memory traffic
+    // (in range they fetched 2/nk extra bytes per tile: PMC read 1.35x the algorithmic bytes on the K = 384 layers).
     auto stageA = [&](int g, char* slot, int kt) {
-        const unsigned ko = (unsigned)kt * 128u;
+        const unsigned ko = kt < nk ? (unsigned)kt * 128u : G8_OOB;
         g8_dma(rw, slot + dma_lds[0], vA[g][0] + ko);
         g8_dma(rw, slot + dma_lds[1], vA[g][1] + ko);
     };
     auto stageB = [&](int h, char* slot, int kt) {
-        const unsigned ko = (unsigned)kt * 128u;
+        const unsigned ko = kt < nk ? (unsigned)kt * 128u : G8_OOB;
         g8_dma(rx, slot + dma_lds[0], vB[h][0] + ko);
         g8_dma(rx, slot + dma_lds[1], vB[h][1] + ko);
     };

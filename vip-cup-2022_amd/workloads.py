@@ -248,10 +248,15 @@ def measure_peaks(ms_budget: float = 50.0) -> Dict[str, float]:
     src = torch.empty((nbytes,), dtype=torch.uint8, device="cuda").random_(0, 255)
     dst = torch.empty_like(src)
 
-    def timed(fn, reps):
+    def timed(fn, budget_ms):
         fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        reps = max(3, min(200, int(budget_ms / max(e0.elapsed_time(e1), 1e-3))))
         e0.record()
         for _ in range(reps):
             fn()
@@ -260,12 +265,12 @@ def measure_peaks(ms_budget: float = 50.0) -> Dict[str, float]:
         return e0.elapsed_time(e1) / reps
 
     t_copy = timed(lambda: _abi.check(lib.vip_microbench_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), "vip_microbench_copy"),
-                   max(3, int(ms_budget / 0.4)))
+                   ms_budget)
     sink = torch.zeros((16,), dtype=torch.float32, device="cuda")
     flops = C.c_double(0.0)
     iters = 2000
     t_mfma = timed(lambda: _abi.check(lib.vip_microbench_mfma_f16(sink.data_ptr(), iters, C.byref(flops), st), "vip_microbench_mfma_f16"),
-                   max(3, int(ms_budget / 0.3)))
+                   ms_budget)
     del src, dst
     return {"hbm_gbs_measured": 2.0 * nbytes / (t_copy * 1e-3) / 1e9, "mfma_tflops_measured": flops.value / (t_mfma * 1e-3) / 1e12}
 
