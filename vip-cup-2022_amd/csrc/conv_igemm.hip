@@ -1180,7 +1180,7 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
         VIP_REQUIRE(!y_lo_off, VIP_ERR_UNSUPPORTED, "vip_gemm_split_f16: at most 256 rows, N %% 4 == 0");
         if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) VIP_PICK("pw_gemm_kernel", launch_pw_k<4>(a, mode, s));
         // deep K, wide N: the LDS-DMA kernel (gemm8p.hpp).  VIP_G8P_MINK: smallest K it takes (0 = never).
-        static const int g8_min_k = getenv("VIP_G8P_MINK") ? atoi(getenv("VIP_G8P_MINK")) : 384;
+        static const int g8_min_k = getenv("VIP_G8P_MINK") ? atoi(getenv("VIP_G8P_MINK")) : 256;
         if (mode >= 0 && g8_min_k > 0 && !gate && a.K >= g8_min_k && gemm8p_eligible(a) && cout_g % 256 == 0 &&
             (long)((M + 255) / 256) * (cout_g / 256) >= 128)
             VIP_PICK("gemm8p_kernel", launch_gemm8p(a, mode, s));
