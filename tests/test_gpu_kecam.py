@@ -124,12 +124,17 @@ def test_kecam_legacy_configs_reduced_depth(report):
 
 
 def test_efficientnet_v2l_full_depth(report):
-    """EfficientNetV2L (efficientnet_v2.py:313-325; a member of the earlier ensembles, main.py:43-56) at FULL depth (79 blocks), 2 images:
-    the seeded weights keep its activations inside fp16 range (oracle max 6.2e3), so the whole graph can be held to the oracle."""
+    """EfficientNetV2L (efficientnet_v2.py:313-325; a member of the earlier ensembles, main.py:43-56) at FULL depth (79 blocks), 2 images.
+    With the seeded weights as generated the 6x-expanded hidden tensors of the late stages leave fp16 range (trunk rms 6e3 at the end; a
+    trained checkpoint does not do that), so the residual branches' projection kernels are halved here - in the ONE dict both the oracle
+    and the product read - which keeps the whole 79-block graph comparable."""
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops, zoo
     spec = zoo.MEMBERS["efficientnet_v2l"]
     p = spec.synth(spec.seed)
+    for k in list(p):
+        if k.endswith("MB_pw_conv/kernel") or k.endswith("fu_conv/kernel"):
+            p[k] = p[k] * 0.5
     x = _images(2, 200).to(torch.float16).to(torch.float32)
     ca, cb = [], []
     with torch.no_grad():
