@@ -269,36 +269,6 @@ def test_dense_gemm8p(M, K, N, mode, report):
     assert torch.equal(got, got2), "two launches on the same operands must agree bit for bit (no race in the DMA ring)"
 
 
-# the mid-size LDS-DMA kernel (csrc/gemm4p.hpp: 128 x 128 x 64 tiles, two workgroups per CU; K % 64 == 0, N % 128 == 0, >= 512 tiles)
-@pytest.mark.parametrize("mode", ["gelu", "res", "relu"])
-@pytest.mark.parametrize("M,K,N", [(50176 + 77, 256, 384), (43264, 128, 768), (70000, 448, 128), (66000, 1536, 384), (65536, 64 * 3, 640)])
-def test_dense_gemm4p(M, K, N, mode, report, monkeypatch):
-    ops = _ops()
-    from vipcup_amd import _abi
-    monkeypatch.setenv("VIP_G4P_MINK", "128")
-    g = torch.Generator().manual_seed(M + K + N)
-    x = h(torch.randn(M, K, generator=g))
-    w = h(torch.randn(K, N, generator=g) / math.sqrt(K))
-    b = torch.randn(N, generator=g) * 0.1
-    cw = ops.make_dense_weight(w, b)
-    d = _abi.ConvDesc(B=M, H=1, W=1, Cin=K, Cout=N, kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Ho=1, Wo=1, groups=1, ldx=K, cin_off=0, ldy=N,
-                      cout_off=0, ldr=N if mode == "res" else 0, res_off=0, ldw=cw.ldw,
-                      act_pre={"gelu": 3, "relu": 1}.get(mode, 0), act_post=0)
-    assert ops.conv_kernel_name(d, mode == "res") == "gemm4p_kernel"
-    if mode == "res":
-        res = h(torch.randn(M, N, generator=g))
-        ref = R.dense(x, w, b) + res
-        got = ops.dense(dev(x), cw, residual=dev(res))
-        got2 = ops.dense(dev(x), cw, residual=dev(res))
-    else:
-        ref = R.act(R.dense(x, w, b), mode)
-        got = ops.dense(dev(x), cw, act=mode)
-        got2 = ops.dense(dev(x), cw, act=mode)
-    torch.cuda.synchronize()
-    check(report, f"dense-gemm4p {mode} {M}x{K}x{N}", got, ref)
-    assert torch.equal(got, got2)
-
-
 # fused MLP (hidden tensor in registers): LDS-resident (C 64/96) and streamed (C 192) weights, M tails, with/without residual, vs two fp32 denses
 @pytest.mark.parametrize("use_ln", [False, True])
 @pytest.mark.parametrize("M,C,hid,use_res", [(8192, 96, 384, True), (20011, 96, 384, False), (9000, 64, 256, True),

@@ -980,7 +980,6 @@ int launch_pwk_conv(const ConvArgs& a0, int mode, int groups, hipStream_t s) {
 }
 
 #include "gemm8p.hpp"
-#include "gemm4p.hpp"
 
 // ---- Dense / 1x1 layers with at most 256 rows (the squeeze-excite and ECA layers: M = batch) ------------------------
 // On the tile kernels such a layer is ONE m-block: 2..16 workgroups walk K chunk by chunk behind a barrier each, 30-100
@@ -1185,12 +1184,6 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
         if (mode >= 0 && g8_min_k > 0 && !gate && a.K >= g8_min_k && gemm8p_eligible(a) && cout_g % 256 == 0 &&
             (long)((M + 255) / 256) * (cout_g / 256) >= 128)
             VIP_PICK("gemm8p_kernel", launch_gemm8p(a, mode, s));
-        // mid-size layers: the 128 x 128 LDS-DMA kernel, two workgroups per CU (gemm4p.hpp).  VIP_G4P_MINK: smallest K (0 = never)
-        const char* g4_env = getenv("VIP_G4P_MINK");     // read per call: tests switch it
-        const int g4_min_k = g4_env ? atoi(g4_env) : 0;
-        if (mode >= 0 && g4_min_k > 0 && !gate && a.K >= g4_min_k && gemm8p_eligible(a) && cout_g % 128 == 0 &&
-            (long)((M + 127) / 128) * (cout_g / 128) >= 512)
-            VIP_PICK("gemm4p_kernel", launch_gemm4p(a, mode, s));
         if (mode >= 0 && (pw_mode & 2) && a.x_span_bytes < 0xFFFFFFF0L) {
             // (a 64 x 256 wave tile at one wave per SIMD - NG = 4 - measured 15-40 % slower than NG = 2 at two)
             static const int xl_min_k = getenv("VIP_PWK_XLK") ? atoi(getenv("VIP_PWK_XLK")) : 768;
