@@ -141,3 +141,38 @@ def test_reference_loop_on_the_seams(tmp_path, report):
     d_or = np.abs(_logit(pred[:, 0]) - z).max()
     report(f"[seams] reference loop on build_dataset/predict: max|dp| vs score_files {d_direct:.2e}, max|dz| vs oracle {d_or:.2e}")
     assert d_direct <= 1e-3 and d_or <= MEMBER_CEILING[key]   # the padded last batch has another row count (other kernels)
+
+
+@pytest.mark.parametrize("shard", ["members", "hybrid"])
+def test_cli_two_ranks_share_the_card(tmp_path, shard, report):
+    """The N > 1 control flow of the drop-in CLI with real members on the GPU: two ranks (gloo; RCCL refuses two ranks per device)
+    score 12 images under `--shard members|hybrid`; the continuous scores must equal the single-process run's - bit for bit under
+    `members` (same kernels, same batches), to fp16 noise under `hybrid` (other batch compositions) - and exactly one all-gather runs."""
+    import subprocess
+    import sys
+    names = []
+    for i in range(12):
+        n = f"img_{500 + i:05d}.jpg"
+        (tmp_path / n).write_bytes(synth_jpeg(500 + i))
+        names.append(n)
+    (tmp_path / "test.csv").write_text("filename\n" + "\n".join(names) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "vip-cup-2022_amd", "main.py")
+    cfg = tmp_path / "ckpts3.json"           # three members keep the two model builds per rank short
+    cfg.write_text('[["ResNetRS50-200x200", [200, 200], 0], ["ECA_NFNetL0-200x200", [200, 200], 1], ["EfficientNetV2T-200x200", [200, 200], 2]]')
+    common = [str(tmp_path / "test.csv"), "--synthetic", "--ckpt-cfg", str(cfg), "--batch-size", "8"]
+    r1 = subprocess.run([sys.executable, cli, common[0], str(tmp_path / "out1.csv"), *common[1:], "--scores-out", str(tmp_path / "s1.csv")],
+                        capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    env = dict(os.environ, VIP_DIST_BACKEND="gloo")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29733", cli, common[0], str(tmp_path / "out2.csv"), *common[1:], "--shard", shard,
+                         "--scores-out", str(tmp_path / "s2.csv")], capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    a, b = pd.read_csv(tmp_path / "s1.csv"), pd.read_csv(tmp_path / "s2.csv")
+    assert a.filename.tolist() == b.filename.tolist()
+    d = np.abs(a.ensemble_mean.values - b.ensemble_mean.values).max()
+    report(f"[e2e] 2 ranks on one card, --shard {shard}: max|dp| vs the single-process scores = {d:.2e}")
+    assert d == 0.0 if shard == "members" else d <= 1e-3
+    if shard == "members":
+        assert pd.read_csv(tmp_path / "out1.csv").equals(pd.read_csv(tmp_path / "out2.csv"))
