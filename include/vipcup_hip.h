@@ -116,6 +116,14 @@ int vip_gemm_bias_act_f16(const void* A, const void* W, const float* bias, const
 int vip_gemm_split_f16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda,
                        int ldw, int act, void* stream);
 
+/* vip_gemm_split_f16 whose INPUT rows are split too: A is [M][2][K] f16 (hi plane, lo plane - what
+ * vip_global_avgpool_split_f16 or a previous split Dense wrote), v = act((A_hi + A_lo) @ W^T + bias), C [M][2][N] as above.
+ * For the chains of Dense layers on pooled vectors (the first squeeze-excite layer at 1024/2048 channels,
+ * resnet_rs_model.py:150-166; kecam resnest.py:44-57; the ECA Conv1D of kecam attention_layers `eca_module`): a pooled vector's
+ * rounding error is the same for every pixel the gate later scales, so it is not averaged away.  M <= 256, N % 4 == 0, K % 8 == 0. */
+int vip_gemm_split2_f16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int ldw, int act,
+                        void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused two-layer MLP:  y[M,C] = W2 . act(W1 . LN(x) + b1) + b2 (+ residual), hidden tensor never written to memory.
  * LN = the LayerNormalization in front of the MLP (convnext.py:199 `norm`, gcvit block `norm2`, ViT `norm2`) when
@@ -177,12 +185,22 @@ int vip_pool2d_nhwc_f16(const void* x, void* y, int B, int H, int W, int C, int 
  * Replaces GlobalAveragePooling2D (resnet_rs_model.py:150,468) / tfa AdaptiveAveragePooling2D(1). */
 int vip_global_avgpool_f16(const void* x, void* y, int B, int HW, int C, int ldx, void* stream);
 
+/* The same pool with the mean written as two fp16 planes: y [B][2][C], y[b][0][c] = fp16(mean), y[b][1][c] = fp16(mean - hi). */
+int vip_global_avgpool_split_f16(const void* x, void* y, int B, int HW, int C, int ldx, void* stream);
+
 /* Classifier head with fp32 output: out[b,n] = bias[n] + sum_c mean_p(x[b,p,c]) * W[n,c].
  * Replaces GlobalAveragePooling2D + Dense(classes) (resnet_rs_model.py:468-476; gcvit models/gcvit.py:104-113;
  * tfimm convnext.py:432-436) — with HW = 1 it is a plain Dense on [B,C] vectors (vit.py:441-461).
  * x f16 [B,HW,*] pixel stride ldx; W f32 [N][C]; bias f32 [N] or NULL; out f32 [B][N]. C <= 4096. */
 int vip_gap_dense_f32(const void* x, const float* W, const float* bias, float* out, int B, int HW, int C,
                       int ldx, int N, void* stream);
+
+/* The head with a LayerNorm between the pool and the Dense, all fp32:
+ *   out[b,n] = bias[n] + sum_c LN_c(mean_p x[b,p,c]; gamma, beta, eps) * W[n,c]
+ * Replaces GlobalAveragePooling2D -> LayerNormalization -> Dense of tfimm convnext.py:432-436 and kecam hornet.py:166-171.
+ * gamma, beta f32 [C]; the rest as vip_gap_dense_f32. */
+int vip_gap_ln_dense_f32(const void* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias,
+                         float* out, int B, int HW, int C, int ldx, int N, void* stream);
 
 /* y = act( x * scale[b,c] + residual ) — the SE "excite" multiply fused with the block's Add+act.
  * Replaces layers.multiply + Add + Activation (resnet_rs_model.py:183,278-280; gcvit feature.py:70).

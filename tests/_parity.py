@@ -18,7 +18,7 @@ TOL_NORTH_STAR = 1e-3
 # EfficientNetV1-B4 4.4e-3 rms emulated vs 4.3e-3 on the GPU), i.e. the kernels add nothing to it.  Members whose ceiling is above
 # 1e-3 do NOT meet the north-star tolerance member by member; the test reports which, and asserts the ceiling (max over <= 128 images).
 MEMBER_CEILING = {
-    "eca_nfnet_l0": 1.5e-3, "resnet_rs50": 2.5e-3, "convnext_tiny_in22k": 3.5e-3, "resnest50": 4.0e-3,
+    "eca_nfnet_l0": 1.5e-3, "resnet_rs50": 2.5e-3, "convnext_tiny_in22k": 1.5e-3, "resnest50": 4.0e-3,
     "gcvit_tiny": 7.0e-3, "efficientnet_v2t": 1.0e-2, "efficientnet_v1b4": 1.8e-2,
     "vit_tiny_patch16_224": 4.0e-3, "vit_small_patch16_224": 4.0e-3,
 }

@@ -48,12 +48,11 @@ for key in members:
         ops.KEEP_ROUNDING_ERROR = True
         emul_ops.BIAS_CORRECT = False
         with emul_ops.patched(round_act=True):
-            m = CTORS[key](params)
-            ops._CALIB = True
-            m.logits(emul_ops.to_device_nhwc8(cal))
-            ops._CALIB = False
+            m = zoo.calibrate(CTORS[key](params), emul_ops.to_device_nhwc8(cal))
             ze = m.logits(x8)[:, 0].float().numpy()
         ops.KEEP_ROUNDING_ERROR = False
+    if hasattr(model, "offset_calibration"):     # VIP_OFFSET_CALIBRATION=1
+        print(f"{key:22s} offset calibration gpu {model.offset_calibration[0]:+.2e} emul {m.offset_calibration[0]:+.2e}", flush=True)
     print(f"{key:22s} gpu-oracle {st(zg - z)} | emul-oracle {st(ze - z)} | gpu-emul {st(zg - ze)}", flush=True)
     out[key] = {"oracle": z.tolist(), "gpu": zg.tolist(), "emul": ze.tolist()}
 os.makedirs("gpurun_out", exist_ok=True)

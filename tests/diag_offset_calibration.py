@@ -30,34 +30,19 @@ CTORS = {"gcvit_tiny": lambda p: gcvit.GCViTTiny(p, device="cpu"),
          "vit_tiny_patch16_224": lambda p: tm.ViT(p, tm.VIT_CONFIGS["vit_tiny_patch16_224"], device="cpu")}
 
 
-def run(round_act, exact_w, skip=()):
-    emul_ops.BIAS_CORRECT = True
-    emul_ops.EXACT_W = exact_w
-    emul_ops.SKIP_ROUND = set(skip)
-    with emul_ops.patched(round_act=round_act):
-        zz = CTORS[key](params).logits(x8)[:, 0].float()
-    d = (zz - z).numpy()
-    return d
 
-
-def show(label, d):
-    print(f"{label:34s} rms {np.sqrt((d**2).mean()):.2e}  mean {d.mean():+.2e}  std {d.std():.2e}  max {np.abs(d).max():.2e}", flush=True)
-
-
+def stt(d):
+    return f"rms {np.sqrt((d**2).mean()):.2e} mean {d.mean():+.2e} std {d.std():.2e} max {np.abs(d).max():.2e}"
+from vipcup_amd import pipeline
 with torch.no_grad():
     z = ref.predict_logits(key, params, x)[:, 0]
     x8 = emul_ops.to_device_nhwc8(x)
-    ops.KEEP_ROUNDING_ERROR = True
-    show("w32 a16", run(True, True))
-    show("w16 a32", run(False, False))
-    emul_ops.TAP_MEANS = True
-    show("w16 a32, per-tap means", run(False, False))
-    emul_ops.TAP_MEANS = False
-    show("w16 a16", run(True, False))
-    for small in (-1, 7, 14, 28):
-        emul_ops.SKIP_SMALL = small
-        show(f"w32 a16, vectors{'' if small < 0 else f' + maps <= {small}'} exact", run(True, True))
-    emul_ops.SKIP_SMALL = 0
-    for ts in sys.argv[3:]:
-        tags = [t for t in ts.split(",") if t and t != "+"]
-        show(f"w32 a16 except {ts}", run(True, True, tags))
+    calraw = [np.asarray(Image.open(io.BytesIO(synth_jpeg(9000 + i))).convert("RGB")) for i in range(16)]
+    cal = emul_ops.to_device_nhwc8(torch.stack([R.decode_resize_normalize(p, spec.input_hw, spec.input_hw) for p in calraw]).half().float())
+    for off in ("0", "1"):
+        os.environ["VIP_OFFSET_CALIBRATION"] = off
+        ops.KEEP_ROUNDING_ERROR = True
+        with emul_ops.patched(round_act=True):
+            m = zoo.calibrate(CTORS[key](params), cal)
+            ze = m.logits(x8)[:, 0].float()
+        print(key, "offset calib", off, getattr(m, "offset_calibration", None), stt((ze - z).numpy()), flush=True)

@@ -18,7 +18,12 @@ ACTN = {0: None, 1: "relu", 2: "silu", 3: "gelu", 4: "sigmoid", None: None}
 SKIP_ROUND = set()       # diagnostic: operator tags whose outputs are NOT rounded (conv, conv_res, dense, se_hid, se_gate, dw, saa, gap, gate_mul, ln, pool, attn)
 
 
+SKIP_SMALL = 0           # diagnostic: feature maps with H <= SKIP_SMALL (and pooled vectors) are NOT rounded
+
+
 def _r(t, tag="other"):
+    if SKIP_SMALL and (t.dim() < 4 or t.shape[1] <= SKIP_SMALL):      # SKIP_SMALL = -1: only the pooled vectors / gates (no feature map)
+        return t
     return t.to(torch.float16).to(torch.float32) if (ROUND_ACT and tag is not None and tag not in SKIP_ROUND) else t
 
 
@@ -27,11 +32,20 @@ def _an(a):
 
 
 def _w(cw):
+    from vipcup_amd import ops
     k = cw.kh * cw.kw * cw.cin_g
+    if ops._EXACT and cw.exact is not None:               # ops.exact_weights(): the K-doubled twin [w | lo] per tap and group
+        w2 = cw.exact.w.float()[:, :2 * k].reshape(cw.cout, cw.kh * cw.kw, 2, cw.cin_g)
+        return (w2[:, :, 0] + w2[:, :, 1]).reshape(cw.cout, cw.kh, cw.kw, cw.cin_g).permute(1, 2, 3, 0)
     w = cw.w.float() if getattr(cw, "w_lo", None) is None else cw.w.float() + cw.w_lo.float()     # two-term weights
     if EXACT_W and cw.err is not None:
         w = w + cw.err
     return w[:, :k].reshape(cw.cout, cw.kh, cw.kw, cw.cin_g).permute(1, 2, 3, 0)
+
+
+def _b(cw):
+    from vipcup_amd import ops
+    return cw.exact.bias if (ops._EXACT and cw.exact is not None) else cw.bias
 
 
 def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=None, out=None, cin_off=0, cout_off=0,
@@ -40,13 +54,16 @@ def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=
     if gate is not None:
         xx = _r(xx * _gate(gate)[:, None, None, :], "gate_mul")
     _calib(cw, xx)
-    y = R.conv2d(xx, _w(cw), cw.bias, stride, pad, cw.groups)
+    y = R.conv2d(xx, _w(cw), _b(cw), stride, pad, cw.groups)
     if BIAS_CORRECT and not EXACT_W and cw.err is not None:
-        mu = xx.reshape(-1, xx.shape[-1]).mean(0)                                  # [Cin]
         k = cw.kh * cw.kw * cw.cin_g
-        e = cw.err[:, :k].reshape(cw.cout, cw.kh * cw.kw, cw.cin_g)
-        cog = cw.cout // cw.groups
-        corr = torch.stack([(e[o] * mu[(o // cog) * cw.cin_g:(o // cog + 1) * cw.cin_g]).sum() for o in range(cw.cout)])
+        e = cw.err[:, :k].reshape(cw.groups, cw.cout // cw.groups, cw.kh * cw.kw, cw.cin_g)
+        if TAP_MEANS:
+            mu = tap_means(xx, cw.kh, cw.kw, stride, pad, y.shape[1], y.shape[2]).reshape(cw.kh * cw.kw, cw.groups, cw.cin_g)
+            corr = torch.einsum("gotc,tgc->go", e, mu).reshape(cw.cout)
+        else:
+            mu = xx.reshape(-1, xx.shape[-1]).mean(0).reshape(cw.groups, cw.cin_g)
+            corr = torch.einsum("gotc,gc->go", e, mu).reshape(cw.cout)
         y = y + corr
     y = R.act(y, _an(act))
     if residual is not None:
@@ -58,6 +75,21 @@ def conv2d(x, cw, stride=1, pad=(0, 0, 0, 0), act=None, act_post=None, residual=
     return y
 
 
+TAP_MEANS = False
+
+
+def tap_means(xx, kh, kw, stride, pad, Ho, Wo):
+    """[kh*kw, Cin]: mean over images and OUTPUT positions of the input value each filter tap sees (zero where it falls in the padding)"""
+    import torch.nn.functional as F
+    st = (stride, stride) if isinstance(stride, int) else stride
+    xp = F.pad(xx, (0, 0, pad[2], pad[3], pad[0], pad[1]))
+    out = []
+    for i in range(kh):
+        for j in range(kw):
+            out.append(xp[:, i:i + st[0] * (Ho - 1) + 1:st[0], j:j + st[1] * (Wo - 1) + 1:st[1], :].reshape(-1, xx.shape[-1]).mean(0))
+    return torch.stack(out)
+
+
 def _calib(cw, xx):
     """inside the product's ops.calibration(): fold (W32 - W16) . E[x] into the bias, exactly as ops.conv2d / ops.dense do"""
     from vipcup_amd import ops
@@ -67,7 +99,7 @@ def _calib(cw, xx):
 
 def dense(x, cw, act=None, act_post=None, residual=None, tag="dense"):
     _calib(cw, x)
-    y = x @ _w(cw)[0, 0] + (cw.bias if cw.bias is not None else 0)
+    y = x @ _w(cw)[0, 0] + (_b(cw) if _b(cw) is not None else 0)
     if BIAS_CORRECT and not EXACT_W and cw.err is not None:
         y = y + cw.err[:, :x.shape[-1]] @ x.reshape(-1, x.shape[-1]).mean(0)
     y = R.act(y, _an(act))
@@ -94,14 +126,20 @@ def _split(v):
     return torch.stack([hi, (v - hi).to(torch.float16).to(torch.float32)], 1)
 
 
+def dense_split(x, cw, act=None):
+    """[M, K] or split [M, 2, K] rows -> split [M, 2, N]"""
+    return _split(dense(_gate(x), cw, act=act, tag=None))
+
+
 def se_gate(x, fc1, fc2, act1, act2="sigmoid", split=True):
-    # the fused kernel keeps the pooled and hidden vectors in fp32; the wide-gate path rounds them (tags gap / se_hid)
+    # the fused kernel keeps the pooled and hidden vectors in fp32; the wide-gate path carries them as hi/lo planes
     fused = x.shape[-1] * fc1.cout + fc1.cout * fc2.cout <= 256 * 1024
-    pooled = x.reshape(x.shape[0], -1, x.shape[-1]).mean(1) if fused else global_avgpool(x)
-    hid = dense(pooled, fc1, act=act1, tag=None if fused else "se_hid")
-    if not split:
-        return dense(hid, fc2, act=act2, tag="se_gate")
-    return _split(dense(hid, fc2, act=act2, tag=None))
+    if fused:
+        pooled = x.reshape(x.shape[0], -1, x.shape[-1]).mean(1)
+        g = _split(dense(dense(pooled, fc1, act=act1, tag=None), fc2, act=act2, tag=None))
+    else:
+        g = dense_split(dense_split(global_avgpool(x, split=True), fc1, act=act1), fc2, act=act2)
+    return g if split else g[:, 0]
 
 
 def dwconv2d(x, w_khwc, bias, k, stride=1, pad=(0, 0, 0, 0), act=None):
@@ -128,9 +166,16 @@ def pool2d(x, k, stride, pad=(0, 0, 0, 0), mode=0, out_hw=None):
     return _r((F.avg_pool2d(xp, k, stride) / F.avg_pool2d(ones, k, stride)).permute(0, 2, 3, 1).contiguous(), "pool")
 
 
-def global_avgpool(x):
+def global_avgpool(x, split=False):
     B, C = x.shape[0], x.shape[-1]
-    return _r(x.reshape(B, -1, C).mean(1), "gap")
+    v = x.reshape(B, -1, C).mean(1)
+    return _split(v) if split else _r(v, "gap")
+
+
+def gap_ln_dense_f32(x, gamma, beta, eps, w_nc, bias):
+    B, C = x.shape[0], x.shape[-1]
+    v = R.layernorm(x.reshape(B, -1, C).mean(1), gamma, beta, eps)
+    return v @ w_nc.t() + (bias if bias is not None else 0)
 
 
 def gap_dense_f32(x, w_nc, bias):
@@ -206,7 +251,7 @@ def patched(round_act=False):
     global ROUND_ACT
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops
-    names = ["conv2d", "dense", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
+    names = ["conv2d", "dense", "dense_split", "gap_ln_dense_f32", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
              "scale_add_act", "mul", "radix_combine", "window_attention", "mhsa", "vit_tokens", "to_device_nhwc8"]
     saved = {n: getattr(ops, n) for n in names}
     old = ROUND_ACT

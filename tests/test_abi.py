@@ -56,6 +56,10 @@ def test_argument_checks_do_not_need_a_gpu():
     st = lib.vip_se_gate_f16(p, p, None, p, None, p, 4, 49, 32768, 32768, 8, 32768, 32768, 8, 2, 4, 1, None)
     assert st == -3 and b"too wide" in lib.vip_last_error()
     # split-output Dense: a batch of pooled vectors, at most 256 rows
+    st = lib.vip_gemm_split2_f16(p, p, None, p, 257, 64, 64, 64, 4, None)
+    assert st == -3 and b"256" in lib.vip_last_error()
+    assert lib.vip_global_avgpool_split_f16(p, p, 2, 4, 12, 12, None) == -2
+    assert lib.vip_gap_ln_dense_f32(p, p, p, 1e-6, p, None, p, 2, 4, 8192, 8192, 1, None) == -3
     st = lib.vip_gemm_split_f16(p, p, None, p, 257, 64, 64, 64, 64, 4, None)
     assert st == -3 and b"256" in lib.vip_last_error()
     st = lib.vip_mul_f16(p, p, p, 4, 16, 32, 24, 32, 0, 16, 0, None)          # slice 24..40 of a 32-wide row

@@ -47,11 +47,14 @@ SIGNATURES = {
     "vip_mlp_fused_f16": (_i, [_vp, _vp, _vp, _f] + [_vp] * 6 + [_i] * 9 + [_vp]),
     "vip_se_gate_f16": (_i, [_vp] * 6 + [_i] * 11 + [_vp]),
     "vip_gemm_split_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 6 + [_vp]),
+    "vip_gemm_split2_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 5 + [_vp]),
     "vip_dwconv2d_nhwc_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
     "vip_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "vip_pool2d_nhwc_f16": (_i, [_vp, _vp] + [_i] * 13 + [_vp]),
     "vip_global_avgpool_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vip_global_avgpool_split_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_gap_dense_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vip_gap_ln_dense_f32": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vip_scale_add_act_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_scale_add_act2_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vip_scale_add_act3_f16": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -986,6 +986,9 @@ int launch_pwk_conv(const ConvArgs& a0, int mode, int groups, hipStream_t s) {
 // us of pure latency while the chip idles.  Here a workgroup owns 16 output channels for all rows, both MFMA operands
 // are loaded global -> VGPR directly (no LDS staging, no barrier in the loop), K is split over the workgroup's four
 // waves whose partial sums meet in LDS once, and (N/16) x (M/64) workgroups run side by side.
+// XSPLIT: the rows are [M][2][K] - a hi and a lo fp16 plane (what gap_kernel / this kernel write with y_lo_off) - and every weight
+// fragment meets both: the vector keeps ~22 bits through the squeeze-excite / ECA / split-attention chains.
+template <bool XSPLIT>
 __global__ __launch_bounds__(256) void rows_gemm_kernel(ConvArgs a) {
     // workgroup = (16 channels, 64 rows): blockIdx.y = row quarter; its 4 waves split K and meet in LDS.  (One workgroup
     // per channel slab streaming ALL rows was bound by a single CU's L2 bandwidth: 1 MB of activations per workgroup.)
@@ -1028,6 +1031,20 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(ConvArgs a) {
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u].h, xf[u][p].h, acc[p], 0, 0, 0);
+            if constexpr (XSPLIT) {     // the lo plane: K halfs further in the same row
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = (ks0 + u < ks_hi) & ((ks0 + u) * 32 + lq * 8 < a.K);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        xf[u][p].u = __builtin_bit_cast(
+                            uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + (ks0 + u) * 64 + 2 * a.K : OOB, 0, 0));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u].h, xf[u][p].h, acc[p], 0, 0, 0);
+            }
         }
     }
     if (kq > 0) {
@@ -1107,7 +1124,7 @@ static thread_local const char* g_pick = "";
     } while (0)
 
 static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void* w, const float* bias, const void* residual, void* y,
-                       const vip_conv_desc* d, void* stream, const void* w_lo = nullptr) {
+                       const vip_conv_desc* d, void* stream, const void* w_lo = nullptr, bool x_split = false) {
     VIP_REQUIRE(x && w && y && d, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_f16: null pointer");
     VIP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 &&
                     d->sh > 0 && d->sw > 0 && d->Ho > 0 && d->Wo > 0 && d->groups > 0 && d->pt >= 0 && d->pl >= 0,
@@ -1174,10 +1191,11 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
         if (M <= 256 && !residual && !gate && d->act_post == VIP_ACT_NONE && d->ldy % 4 == 0 && d->cout_off % 4 == 0 &&
             a.x_span_bytes < 0xFFFF0000L - 2L * a.K && 2L * cout_g * d->ldw < 0xFFFF0000L - 2L * a.K) {
             if (g_dry) { g_pick = "rows_gemm_kernel"; return VIP_OK; }
-            hipLaunchKernelGGL(rows_gemm_kernel, dim3((unsigned)((cout_g + 15) / 16), (unsigned)((M + 63) / 64)), dim3(256), 0, s, a);
+            if (x_split) hipLaunchKernelGGL(rows_gemm_kernel<true>, dim3((unsigned)((cout_g + 15) / 16), (unsigned)((M + 63) / 64)), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(rows_gemm_kernel<false>, dim3((unsigned)((cout_g + 15) / 16), (unsigned)((M + 63) / 64)), dim3(256), 0, s, a);
             return vip_launch_status("vip_conv2d_nhwc_f16(rows)");
         }
-        VIP_REQUIRE(!y_lo_off, VIP_ERR_UNSUPPORTED, "vip_gemm_split_f16: at most 256 rows, N %% 4 == 0");
+        VIP_REQUIRE(!y_lo_off && !x_split, VIP_ERR_UNSUPPORTED, "vip_gemm_split_f16: at most 256 rows, N %% 4 == 0");
         if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) VIP_PICK("pw_gemm_kernel", launch_pw_k<4>(a, mode, s));
         // deep K, wide N: the LDS-DMA kernel (gemm8p.hpp).  VIP_G8P_MINK: smallest K it takes (0 = never).
         static const int g8_min_k = getenv("VIP_G8P_MINK") ? atoi(getenv("VIP_G8P_MINK")) : 256;
@@ -1272,4 +1290,15 @@ extern "C" int vip_gemm_split_f16(const void* A, const void* W, const float* bia
     d.Ho = d.Wo = 1; d.groups = 1; d.ldx = lda; d.cin_off = 0; d.ldy = 2 * N; d.cout_off = 0; d.ldr = 0;
     d.res_off = 0; d.ldw = ldw; d.act_pre = act; d.act_post = VIP_ACT_NONE;
     return conv2d_impl(A, nullptr, N, W, bias, nullptr, C, &d, stream);
+}
+
+extern "C" int vip_gemm_split2_f16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int ldw, int act,
+                                   void* stream) {
+    VIP_REQUIRE(M > 0 && M <= 256, VIP_ERR_UNSUPPORTED, "vip_gemm_split2_f16: M=%d (1..256 rows)", M);
+    VIP_REQUIRE(K % 8 == 0, VIP_ERR_ALIGNMENT, "vip_gemm_split2_f16: K must be a multiple of 8");
+    vip_conv_desc d;
+    d.B = M; d.H = 1; d.W = 1; d.Cin = K; d.Cout = N; d.kh = d.kw = 1; d.sh = d.sw = 1; d.pt = d.pl = 0;
+    d.Ho = d.Wo = 1; d.groups = 1; d.ldx = 2 * K; d.cin_off = 0; d.ldy = 2 * N; d.cout_off = 0; d.ldr = 0;
+    d.res_off = 0; d.ldw = ldw; d.act_pre = act; d.act_post = VIP_ACT_NONE;
+    return conv2d_impl(A, nullptr, N, W, bias, nullptr, C, &d, stream, nullptr, true);
 }

@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256) void pool2d_kernel(const f16* __restrict__ x, 
 // ---------------------------------------------------------------------------------------------
 // global average pool: block = (image, 64-channel slab); 8 chunk lanes x 32 pixel lanes
 // ---------------------------------------------------------------------------------------------
+// y_lo_off != 0: the mean is written as TWO fp16 planes, hi = fp16(v) at y[b][c] and lo = fp16(v - hi) y_lo_off halfs further (rows
+// of 2 C halfs): a pooled vector feeds a Dense layer directly - its rounding error is not averaged over pixels by anything downstream.
 __global__ __launch_bounds__(256) void gap_kernel(const f16* __restrict__ x, f16* __restrict__ y, int HW, int C,
-                                                  int ldx) {
+                                                  int ldx, int y_lo_off) {
     const int b = blockIdx.y;
     const int c0 = blockIdx.x * 64;
     const int cl = threadIdx.x & 7, pl = threadIdx.x >> 3;
@@ -84,7 +86,13 @@ __global__ __launch_bounds__(256) void gap_kernel(const f16* __restrict__ x, f16
 #pragma unroll
         for (int p = 0; p < 32; ++p) s += red[p][threadIdx.x];
         const int cc = c0 + threadIdx.x;
-        if (cc < C) y[(long)b * C + cc] = (f16)(s / (float)HW);
+        if (cc < C) {
+            const float v = s / (float)HW;
+            const f16 hi = (f16)v;
+            f16* dst = y + (long)b * (y_lo_off ? 2 * C : C) + cc;
+            dst[0] = hi;
+            if (y_lo_off) dst[y_lo_off] = (f16)(v - (float)hi);
+        }
     }
 }
 
@@ -282,8 +290,18 @@ extern "C" int vip_global_avgpool_f16(const void* x, void* y, int B, int HW, int
     VIP_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldx >= C, VIP_ERR_ALIGNMENT,
                 "vip_global_avgpool_f16: C/ldx must be multiples of 8");
     hipLaunchKernelGGL(gap_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y,
-                       HW, C, ldx);
+                       HW, C, ldx, 0);
     return vip_launch_status("vip_global_avgpool_f16");
+}
+
+extern "C" int vip_global_avgpool_split_f16(const void* x, void* y, int B, int HW, int C, int ldx, void* stream) {
+    VIP_REQUIRE(x && y, VIP_ERR_BAD_ARG, "vip_global_avgpool_split_f16: null pointer");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0, VIP_ERR_BAD_ARG, "vip_global_avgpool_split_f16: non-positive dimension");
+    VIP_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldx >= C, VIP_ERR_ALIGNMENT,
+                "vip_global_avgpool_split_f16: C/ldx must be multiples of 8");
+    hipLaunchKernelGGL(gap_kernel, dim3((C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (f16*)y,
+                       HW, C, ldx, C);
+    return vip_launch_status("vip_global_avgpool_split_f16");
 }
 
 extern "C" int vip_scale_add_act3_f16(const void* x, const void* scale, int scale_planes, const void* residual, void* y,
@@ -403,7 +421,73 @@ __global__ __launch_bounds__(256) void gap_dense_kernel(const f16* __restrict__ 
         __syncthreads();
     }
 }
+
+// Classifier head with a LayerNorm between pool and Dense (tfimm ConvNeXt convnext.py:432-436, kecam HorNet): mean over the pixels,
+// LayerNorm over the channels, Dense - all in fp32, one workgroup per image.  The pooled vector is where a rounding error is NOT
+// averaged over pixels any more: rounding it (and the LayerNorm output) to fp16 was 60 % of ConvNeXt-T's logit error.
+__global__ __launch_bounds__(256) void gap_ln_dense_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, const float* __restrict__ Wt,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int HW, int C,
+                                                           int ldx, int N) {
+    __shared__ float pooled[4096];
+    __shared__ float red[2][4];
+    const int b = blockIdx.x;
+    const f16* xb = x + (long)b * HW * ldx;
+    const float inv = 1.f / (float)HW;
+    float s1 = 0.f;
+    for (int c8 = threadIdx.x; c8 < (C >> 3); c8 += 256) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int p = 0; p < HW; ++p) {
+            U4H8 v;
+            v.u = *reinterpret_cast<const uint4*>(xb + (long)p * ldx + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v.e[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            pooled[c8 * 8 + j] = acc[j] * inv;
+            s1 += acc[j] * inv;
+        }
+    }
+    s1 = wave_reduce_sum(s1);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s1;
+    __syncthreads();
+    const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)C;
+    float s2 = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float d = pooled[c] - mean;
+        s2 += d * d;
+    }
+    s2 = wave_reduce_sum(s2);
+    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = s2;
+    __syncthreads();
+    const float rstd = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)C + eps);
+    for (int c = threadIdx.x; c < C; c += 256) pooled[c] = (pooled[c] - mean) * rstd * gamma[c] + beta[c];
+    __syncthreads();
+    for (int n = 0; n < N; ++n) {
+        float s = 0.f;
+        for (int c = threadIdx.x; c < C; c += 256) s += pooled[c] * Wt[(long)n * C + c];
+        s = wave_reduce_sum(s);
+        if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[(long)b * N + n] = red[0][0] + red[0][1] + red[0][2] + red[0][3] + (bias ? bias[n] : 0.f);
+        __syncthreads();
+    }
+}
 }  // namespace
+
+extern "C" int vip_gap_ln_dense_f32(const void* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias,
+                                    float* out, int B, int HW, int C, int ldx, int N, void* stream) {
+    VIP_REQUIRE(x && gamma && beta && W && out, VIP_ERR_BAD_ARG, "vip_gap_ln_dense_f32: null pointer");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && N > 0 && eps >= 0.f, VIP_ERR_BAD_ARG, "vip_gap_ln_dense_f32: bad dimension or eps");
+    VIP_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldx >= C, VIP_ERR_ALIGNMENT, "vip_gap_ln_dense_f32: C/ldx must be multiples of 8");
+    VIP_REQUIRE(C <= 4096, VIP_ERR_UNSUPPORTED, "vip_gap_ln_dense_f32: C=%d > 4096", C);
+    hipLaunchKernelGGL(gap_ln_dense_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const f16*)x, gamma, beta, eps, W, bias, out,
+                       HW, C, ldx, N);
+    return vip_launch_status("vip_gap_ln_dense_f32");
+}
 
 extern "C" int vip_gap_dense_f32(const void* x, const float* W, const float* bias, float* out, int B, int HW, int C,
                                  int ldx, int N, void* stream) {

@@ -136,8 +136,8 @@ class HorNet:
         return y
 
     def logits(self, x):
-        v = self.head_ln(ops.global_avgpool(self.features(x)))              # avg_pool -> pre_output_ln -> Dense  (:166-171)
-        return ops.gap_dense_f32(v.reshape(v.shape[0], 1, 1, -1), self.head_w, self.head_b)
+        n = self.head_ln                                                    # avg_pool -> pre_output_ln -> Dense  (:166-171), fp32
+        return ops.gap_ln_dense_f32(self.features(x), n.g, n.b, LN_EPS, self.head_w, self.head_b)
 
     def predict(self, x):
         z = self.logits(x)

@@ -448,7 +448,7 @@ class NormFreeNet(_Base):
             d = ops.conv2d(d, blk["d2"], stride=s, pad=PAD1, act=act)
             d = ops.conv2d(d, blk["d3"], pad=PAD1, act=act)
             d = ops.conv2d(d, blk["d4"])
-            a = ops.dense(ops.global_avgpool(d), blk["eca"], act="sigmoid")
+            a = ops.dense_split(ops.global_avgpool(d, split=True), blk["eca"], act="sigmoid")   # pooled vector and gate: hi/lo planes
             if bi + 1 < len(self.blocks):      # the next block's act(x) is a second output of this launch
                 y, pre = ops.scale_add_act(d, a, sc, None, act2=act)
             else:

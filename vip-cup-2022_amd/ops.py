@@ -58,6 +58,7 @@ class ConvWeight:
     alg_cin_g: int = 0   # un-padded input channels per group (algorithmic FLOP count)
     err: Optional[torch.Tensor] = None   # fp32 [cout, ldw]: (fp32 weight - stored fp16 weight), kept only until calibrate()
     w_lo: Optional[torch.Tensor] = None  # fp16 [cout, ldw]: fp16(W32 - w) for the two-term-weight kernel (see make_conv_weight)
+    exact: Optional["ConvWeight"] = None  # calibration only (exact_weights()): [w | fp16(W32 - w)] along K, the uncorrected bias
 
     @property
     def cin(self):
@@ -70,6 +71,9 @@ class ConvWeight:
 
 KEEP_ROUNDING_ERROR = False   # set while a model is constructed for bias calibration: ConvWeight.err is populated
 _CALIB = False                # inside calibration(): conv/dense fold  (W32 - W16) . E[x]  into their bias, once
+_UNFUSED = False              # inside calibration() / unfused() / exact_weights(): every Dense / conv is its own launch
+_EXACT = False                # inside exact_weights(): layers run with ConvWeight.exact (two-term weights, K doubled)
+_EXACT_REG: list = []         # the ConvWeights that currently hold an .exact twin (dropped by drop_exact_weights())
 
 
 class calibration:
@@ -82,15 +86,65 @@ class calibration:
     Standard post-training-quantisation bias correction; it needs inputs, not labels."""
 
     def __enter__(self):
-        global _CALIB
-        self._old = _CALIB
-        _CALIB = True
+        global _CALIB, _UNFUSED
+        self._old = (_CALIB, _UNFUSED)
+        _CALIB = _UNFUSED = True
         return self
 
     def __exit__(self, *exc):
-        global _CALIB
-        _CALIB = self._old
+        global _CALIB, _UNFUSED
+        _CALIB, _UNFUSED = self._old
         return False
+
+
+class unfused:
+    """Context: the launch structure of calibration() (MLP and squeeze-excite chains as separate Dense launches, gates multiplied
+    in before the convolution) without touching any bias - the fp16-weight leg of the whole-model offset (zoo.calibrate)."""
+
+    def __enter__(self):
+        global _UNFUSED
+        self._old = _UNFUSED
+        _UNFUSED = True
+        return self
+
+    def __exit__(self, *exc):
+        global _UNFUSED
+        _UNFUSED = self._old
+        return False
+
+
+class exact_weights:
+    """Context: the same launches as unfused(), every layer that went through calibration() with ~22-bit weights: its ``exact`` twin
+    holds ``[w | fp16(W32 - w)]`` per filter tap and group along K, the input channels are fed twice, and the SAME kernels accumulate
+    both terms in fp32 and round the output where the fp16-weight layer rounds it.  Twice the K, so calibration only: the difference
+    of the two legs' mean logits is what the layer-wise bias correction leaves of the weight rounding (second-order through the
+    nonlinearities, border taps), an offset shared by all images, and goes into the head bias."""
+
+    def __enter__(self):
+        global _UNFUSED, _EXACT
+        self._old = (_UNFUSED, _EXACT)
+        _UNFUSED = _EXACT = True
+        return self
+
+    def __exit__(self, *exc):
+        global _UNFUSED, _EXACT
+        _UNFUSED, _EXACT = self._old
+        return False
+
+
+def drop_exact_weights():
+    """free the calibration-only twins"""
+    for cw in _EXACT_REG:
+        cw.exact = None
+    _EXACT_REG.clear()
+
+
+def _exact_operands(x: torch.Tensor, cw: "ConvWeight", cin_off: int = 0):
+    """(x with every group's channels repeated, the K-doubled twin, cin_off = 0)"""
+    xs = x[..., cin_off:cin_off + cw.cin]
+    lead = xs.shape[:-1]
+    xg = xs.reshape(*lead, cw.groups, cw.cin_g)
+    return torch.cat([xg, xg], -1).reshape(*lead, 2 * cw.cin).contiguous(), cw.exact, 0
 
 
 def _bias_correct(cw: "ConvWeight", x_eff: torch.Tensor):
@@ -98,6 +152,14 @@ def _bias_correct(cw: "ConvWeight", x_eff: torch.Tensor):
     mu = x_eff.reshape(-1, x_eff.shape[-1]).float().mean(0)                       # [cin]
     k = cw.kh * cw.kw * cw.cin_g
     cog = cw.cout // cw.groups
+    taps = cw.kh * cw.kw
+    w2 = torch.cat([cw.w[:, :k].reshape(cw.cout, taps, cw.cin_g), cw.err[:, :k].to(torch.float16).reshape(cw.cout, taps, cw.cin_g)], 2)
+    w2 = w2.reshape(cw.cout, 2 * k)
+    if (2 * k) % 8:
+        w2 = torch.cat([w2, w2.new_zeros(cw.cout, 8 - (2 * k) % 8)], 1)
+    cw.exact = ConvWeight(w=w2.contiguous(), bias=cw.bias, kh=cw.kh, kw=cw.kw, cin_g=2 * cw.cin_g, cout=cw.cout, groups=cw.groups,
+                          alg_cin_g=cw.alg_cin_g)
+    _EXACT_REG.append(cw)
     e = cw.err[:, :k].reshape(cw.groups, cog, cw.kh * cw.kw, cw.cin_g)
     corr = (e * mu.reshape(cw.groups, 1, 1, cw.cin_g)).sum((2, 3)).reshape(cw.cout)
     cw.bias = corr if cw.bias is None else (cw.bias + corr)
@@ -206,6 +268,13 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
     ``x`` may carry more channels than the weight consumes (``cin_off`` selects the slice); ``out`` may
     be a wider tensor written at ``cout_off`` (concat-free channel splits / joins)."""
     _chk16(x, "conv2d.x")
+    if gate is not None and _UNFUSED:
+        assert gate.shape == (x.shape[0], 2, cw.cin) and x.shape[3] == cw.cin and cin_off == 0
+        x, gate = scale_add_act(x, gate, None, None), None
+    if _CALIB and cw.err is not None:
+        _bias_correct(cw, x[..., cin_off:cin_off + cw.cin])
+    if _EXACT and cw.exact is not None:
+        x, cw, cin_off = _exact_operands(x, cw, cin_off)
     B, H, W, ldx = x.shape
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     pt, pb, pl, pr = pad
@@ -218,11 +287,9 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
     if gate is not None:
         _chk16(gate, "conv2d.gate")
         assert gate.shape == (B, 2, cw.cin) and ldx == cw.cin and cin_off == 0
-        if _CALIB or conv_kernel_name(d, residual is not None, has_gate=True) is None:
+        if conv_kernel_name(d, residual is not None, has_gate=True) is None:
             x = scale_add_act(x, gate, None, None)
             gate = None
-    if _CALIB and cw.err is not None:
-        _bias_correct(cw, x[..., cin_off:cin_off + cw.cin])
     if out is None:
         out = torch.empty((B, Ho, Wo, cw.cout), dtype=torch.float16, device=x.device)
     else:
@@ -259,11 +326,13 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
 def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Optional[torch.Tensor] = None):
     """Dense over the last axis of ``x`` (any leading shape)."""
     _chk16(x, "dense.x")
+    if _CALIB and cw.err is not None:
+        _bias_correct(cw, x)
+    if _EXACT and cw.exact is not None:
+        x, cw, _ = _exact_operands(x, cw)
     lead = x.shape[:-1]
     K = x.shape[-1]
     M = x.numel() // K
-    if _CALIB and cw.err is not None:
-        _bias_correct(cw, x)
     out = torch.empty((*lead, cw.cout), dtype=torch.float16, device=x.device)
     ldr = 0
     if residual is not None:
@@ -295,7 +364,7 @@ def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual:
     C_ = x.shape[-1]
     M = x.numel() // C_
     hid = fc1.cout
-    if (not _CALIB and fc2.cout == C_ and fc1.groups == 1 and fc2.groups == 1 and x.is_contiguous()
+    if (not _UNFUSED and fc2.cout == C_ and fc1.groups == 1 and fc2.groups == 1 and x.is_contiguous()
             and _abi.lib().vip_mlp_fused_supported(M, C_, hid, _act(act))):
         out = torch.empty_like(x)
         if residual is not None:
@@ -330,9 +399,10 @@ def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmo
     B, H, W, Cc = x.shape
     assert fc1.groups == 1 and fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1
     assert fc1.cin == Cc and fc2.cin == fc1.cout, (fc1.cin, Cc, fc2.cin, fc1.cout)
-    if _CALIB or Cc * fc1.cout + fc1.cout * fc2.cout > 256 * 1024:
-        hid = dense(global_avgpool(x), fc1, act=act1)
-        return dense_split(hid, fc2, act=act2) if split else dense(hid, fc2, act=act2)
+    if _UNFUSED or Cc * fc1.cout + fc1.cout * fc2.cout > 256 * 1024:
+        # pooled and hidden vectors as hi/lo planes too (the one-launch kernel keeps them in fp32)
+        g = dense_split(dense_split(global_avgpool(x, split=True), fc1, act=act1), fc2, act=act2)
+        return g if split else g[:, 0].contiguous()
     out = torch.empty((B, 2, fc2.cout) if split else (B, fc2.cout), dtype=torch.float16, device=x.device)
     st = _abi.lib().vip_se_gate_f16(_p(x), _p(fc1.w), _p(fc1.bias), _p(fc2.w), _p(fc2.bias), _p(out), B, H * W, Cc, Cc,
                                     fc1.cout, fc1.ldw, fc2.cout, fc2.ldw, _act(act1), _act(act2), int(split), _stream())
@@ -341,17 +411,26 @@ def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmo
 
 
 def dense_split(x: torch.Tensor, cw: ConvWeight, act=None) -> torch.Tensor:
-    """Dense on a few rows ``[M, K]`` with the output as two fp16 planes ``[M, 2, N]`` (``fp16(v)``, ``fp16(v - fp16(v))``)."""
+    """Dense on a few rows with the output as two fp16 planes ``[M, 2, N]`` (``fp16(v)``, ``fp16(v - fp16(v))``).  ``x`` is ``[M, K]``
+    or itself split, ``[M, 2, K]`` (a pooled vector from ``global_avgpool(split=True)`` or the previous layer of the chain)."""
     _chk16(x, "dense_split.x")
-    M, K = x.shape
+    split_in = x.dim() == 3
+    assert x.dim() == 2 or (split_in and x.shape[1] == 2), x.shape
     if _CALIB and cw.err is not None:
-        _bias_correct(cw, x)
+        _bias_correct(cw, x.float().sum(1) if split_in else x)
+    if _EXACT and cw.exact is not None:
+        x, cw, _ = _exact_operands(x, cw)
+    M, K = x.shape[0], x.shape[-1]
     out = torch.empty((M, 2, cw.cout), dtype=torch.float16, device=x.device)
-    for m0 in range(0, M, 256):       # the C entry point takes at most 256 rows (a batch of pooled vectors)
+    for m0 in range(0, M, 256):       # the C entry points take at most 256 rows (a batch of pooled vectors)
         m1 = min(M, m0 + 256)
-        st = _abi.lib().vip_gemm_split_f16(_p(x[m0:m1]), _p(cw.w), _p(cw.bias), _p(out[m0:m1]), m1 - m0, cw.cout, K, K,
-                                           cw.ldw, _act(act), _stream())
-        _abi.check(st, "vip_gemm_split_f16")
+        if split_in:
+            st = _abi.lib().vip_gemm_split2_f16(_p(x[m0:m1]), _p(cw.w), _p(cw.bias), _p(out[m0:m1]), m1 - m0, cw.cout, K,
+                                                cw.ldw, _act(act), _stream())
+        else:
+            st = _abi.lib().vip_gemm_split_f16(_p(x[m0:m1]), _p(cw.w), _p(cw.bias), _p(out[m0:m1]), m1 - m0, cw.cout, K, K,
+                                               cw.ldw, _act(act), _stream())
+        _abi.check(st, "vip_gemm_split2_f16" if split_in else "vip_gemm_split_f16")
     return out
 
 
@@ -402,14 +481,15 @@ def pool2d(x, k: int, stride: int, pad=(0, 0, 0, 0), mode=POOL_MAX_ZEROPAD, out_
     return out
 
 
-def global_avgpool(x):
-    """[B,H,W,C] (or [B,N,C]) -> [B,C]"""
+def global_avgpool(x, split: bool = False):
+    """[B,H,W,C] (or [B,N,C]) -> [B,C]; ``split``: [B,2,C], the mean as a hi and a lo fp16 plane (for ``dense_split``)."""
     _chk16(x, "global_avgpool.x")
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
-    out = torch.empty((B, Cc), dtype=torch.float16, device=x.device)
-    st = _abi.lib().vip_global_avgpool_f16(_p(x), _p(out), B, HW, Cc, Cc, _stream())
-    _abi.check(st, "vip_global_avgpool_f16")
+    out = torch.empty((B, 2, Cc) if split else (B, Cc), dtype=torch.float16, device=x.device)
+    fn = "vip_global_avgpool_split_f16" if split else "vip_global_avgpool_f16"
+    st = getattr(_abi.lib(), fn)(_p(x), _p(out), B, HW, Cc, Cc, _stream())
+    _abi.check(st, fn)
     return out
 
 
@@ -424,6 +504,22 @@ def gap_dense_f32(x, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
     st = _abi.lib().vip_gap_dense_f32(_p(x), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, N, _stream())
     _abi.check(st, "vip_gap_dense_f32")
+    return out
+
+
+def gap_ln_dense_f32(x, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Classifier head with a LayerNorm on the pooled vector: mean over the middle axes of ``x`` ([B,...,C]) -> LayerNorm over C
+    -> Dense, fp32 throughout -> fp32 ``[B,N]``.  ``gamma``/``beta`` fp32 ``[C]``, ``w_nc`` fp32 ``[N,C]``."""
+    _chk16(x, "gap_ln_dense_f32.x")
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    N = w_nc.shape[0]
+    assert w_nc.dtype == torch.float32 and w_nc.shape == (N, Cc) and w_nc.is_contiguous()
+    assert gamma.dtype == beta.dtype == torch.float32 and gamma.shape == beta.shape == (Cc,)
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    st = _abi.lib().vip_gap_ln_dense_f32(_p(x), _p(gamma), _p(beta), float(eps), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, N,
+                                         _stream())
+    _abi.check(st, "vip_gap_ln_dense_f32")
     return out
 
 

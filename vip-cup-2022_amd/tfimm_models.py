@@ -228,8 +228,8 @@ class ConvNeXt:
 
     def logits(self, x):
         f = self.features(x)                                                      # pool -> norm -> fc (:432-436)
-        pooled = self.head_norm(ops.global_avgpool(f))
-        return ops.gap_dense_f32(pooled, self.head_w, self.head_b)
+        n = self.head_norm
+        return ops.gap_ln_dense_f32(f, n.g, n.b, LN_EPS, self.head_w, self.head_b)
 
     def predict(self, x):
         z = self.logits(x)

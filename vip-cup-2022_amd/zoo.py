@@ -139,10 +139,33 @@ def construct(spec: MemberSpec, params, bias_calibration: bool = True):
         model = spec.ctor(params)
     finally:
         ops.KEEP_ROUNDING_ERROR = False
-    x = pipeline.calibration_batch().resized(spec.input_hw, spec.input_hw)
+    calibrate(model, pipeline.calibration_batch().resized(spec.input_hw, spec.input_hw))
+    torch.cuda.synchronize()
+    return model
+
+
+def calibrate(model, x):
+    """The two calibration steps of a freshly constructed model (built under ``ops.KEEP_ROUNDING_ERROR``) on the batch ``x``:
+    1. layer-wise: every conv / dense folds (W32 - W16) . E[input] into its fp32 bias (``ops.calibration``);
+    2. whole-model, only with ``VIP_OFFSET_CALIBRATION=1``: what is left of the weight rounding at the logit is, to first order, the
+       same offset for every image (the layer-wise step cannot see the part that goes through the nonlinearities and the zero-padded
+       border taps).  Two more passes over the same batch with identical launches - fp16 weights as shipped (``ops.unfused``) and
+       two-term ~22-bit weights with the uncorrected biases (``ops.exact_weights``) - and the difference of their mean logits is
+       added to the head bias.  Inputs only, no labels, nothing but this library's own kernels.  OFF by default: measured on 64
+       images it removes the weight offset (ResNeSt mean |dz| 8.9e-4 -> 6.6e-4, NFNet 2.2e-4 -> 1.9e-4) but on ResNet-RS-50 and
+       GCViT that offset was cancelling part of the activation-rounding offset (5.0e-4 -> 6.8e-4, 1.37e-3 -> 1.47e-3), and on
+       the EfficientNets the two legs' activation roundings differ by as much as the offset being estimated."""
+    from . import ops
     with ops.calibration():
         model.logits(x)
-    torch.cuda.synchronize()
+    if os.environ.get("VIP_OFFSET_CALIBRATION", "0") == "1":
+        with ops.unfused():
+            z16 = model.logits(x).float()
+        with ops.exact_weights():
+            z22 = model.logits(x).float()
+        model.head_b = (model.head_b + (z22 - z16).mean(0)[:model.head_b.numel()]).contiguous()
+        model.offset_calibration = (z22 - z16).mean(0).tolist()
+    ops.drop_exact_weights()
     return model
 
 
