@@ -5,6 +5,7 @@ fp16 rounding of the output: tolerance = 2e-3 relative to the output scale (fp16
 relative precision).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -356,6 +357,33 @@ def test_dwconv(k, s, C, H, report):
     got = ops.dwconv2d(dev(x), w[..., 0].contiguous().cuda(), b.cuda(), k, s, (p, p, p, p), act="gelu")
     torch.cuda.synchronize()
     check(report, f"dwconv k{k} s{s} C{C}", got, ref)
+
+
+# the matrix-core depthwise kernel (k 7 / 5, stride 1, C % 16 == 0): tile tails in both axes, maps smaller than a tile, several
+# tiles per image and several images per band, asymmetric padding (TF SAME on even sizes is symmetric here; VALID = no padding),
+# every activation epilogue; the filter is fp32 at the boundary and the kernel carries it as hi + lo fp16 - checked to 1e-3 of |y|max
+@pytest.mark.parametrize("k,C,H,W,B,pad,act", [(7, 96, 35, 21, 3, (3, 3, 3, 3), None), (7, 32, 7, 7, 5, (3, 3, 3, 3), "gelu"),
+                                               (7, 16, 50, 17, 2, (0, 0, 0, 0), "relu"), (7, 48, 16, 16, 9, (2, 4, 1, 5), "silu"),
+                                               (5, 336, 14, 14, 2, (2, 2, 2, 2), "silu"), (5, 16, 33, 40, 3, (1, 3, 4, 0), None),
+                                               (5, 80, 3, 19, 4, (2, 2, 2, 2), "sigmoid")])
+def test_dwconv_matrix_cores(k, C, H, W, B, pad, act, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(k * 1000 + C + H)
+    x = h(torch.randn(B, H, W, C, generator=g) + 0.3)
+    w = torch.randn(k, k, C, 1, generator=g) / k
+    b = torch.randn(C, generator=g) * 0.1
+    ref = R.act(R.dwconv2d(x, w, b, 1, pad), act)
+    os.environ["VIP_DW_MFMA"] = "1"                      # opt-in kernel (read per call)
+    try:
+        got = ops.dwconv2d(dev(x), w[..., 0].contiguous().cuda(), b.cuda(), k, 1, pad, act=act)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["VIP_DW_MFMA"]
+    assert got.shape == ref.shape
+    check(report, f"dwconv(mfma) k{k} C{C} {H}x{W} B{B} pad{pad} {act}", got, ref, tol=1e-3)
+    valu = ops.dwconv2d(dev(x), w[..., 0].contiguous().cuda(), b.cuda(), k, 1, pad, act=act)   # the default (VALU) kernel
+    torch.cuda.synchronize()
+    assert (got.float() - valu.float()).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("C", [64, 96, 128, 192, 256, 384, 512, 768, 1024, 2048])

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (side effect: HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvipcup_hip.so")
+LIB_PATH = os.environ.get("VIP_LIB_PATH") or os.path.join(_HERE, "libvipcup_hip.so")   # VIP_LIB_PATH: kernel A/B builds
 
 _lib = None
 

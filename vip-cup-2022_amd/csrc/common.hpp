@@ -37,6 +37,9 @@ static inline int vip_launch_status(const char* what) {
 // stride-1 depthwise fast path (dwconv.hip); returns 1 when the shape is not handled there
 int vip_dwconv_tiled(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                      int pt, int pl, int Ho, int Wo, int act, hipStream_t s);
+// stride-1 7x7 / 5x5 depthwise on the matrix cores (dwconv_mfma.hip); returns 1 when the shape is not handled there
+int vip_dwconv_mfma(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
+                    int pt, int pl, int Ho, int Wo, int act, hipStream_t s);
 
 // ---- device helpers -------------------------------------------------------------------------
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the fp16 output rounding): 1 rcp + 1 exp2 +

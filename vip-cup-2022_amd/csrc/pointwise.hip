@@ -363,6 +363,8 @@ extern "C" int vip_dwconv2d_nhwc_f16(const void* x, const float* w, const float*
     const float* wi = w;
     f16* yo = (f16*)y;
     if (stride == 1) {
+        const int sm = vip_dwconv_mfma(x, w, bias, y, B, H, W, C, k, pt, pl, Ho, Wo, act, s);
+        if (sm != 1) return sm;
         const int st = vip_dwconv_tiled(x, w, bias, y, B, H, W, C, k, pt, pl, Ho, Wo, act, s);
         if (st != 1) return st;
     }
