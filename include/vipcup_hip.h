@@ -311,6 +311,19 @@ int vip_tta_augment_f16(const void* x, void* y, const int32_t* flags, int B, int
                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Scores.
+ * vip_head_prob_f32: what `model.predict` applies to the logits - sigmoid for one class, softmax otherwise (the Dense(classes,
+ *   activation=...) heads of resnet_rs_model.py:474-476, gcvit models/gcvit.py:109-113, tfimm / kecam classifiers) -> prob [B][N]
+ *   (may be NULL), and main.py:113-114's multi-class -> binary map -> score [B] = N == 1 ? p : 1 - p[:, 0] (may be NULL).
+ * vip_ensemble_mean_f32: mean over the M members of scores [M][ld] -> mean [n] (pd.concat + groupby('filename').mean(),
+ *   main.py:142-143, for images that appear once per member).  All fp32.
+ * vip_prob_to_score_f32: the same map applied to probabilities a model's predict() already returned (prob [B][N] -> score [B]).
+ * ------------------------------------------------------------------------------------------ */
+int vip_head_prob_f32(const float* logits, float* prob, float* score, int B, int N, void* stream);
+int vip_prob_to_score_f32(const float* prob, float* score, int B, int N, void* stream);
+int vip_ensemble_mean_f32(const float* scores, float* mean, int M, int n, long ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Introspection and measurement support (no reference counterpart: the reference leaves kernel choice to cuDNN and
  * has no roofline measurement; SURVEY.md section 8(b) / 8(d) ask for these).
  * ------------------------------------------------------------------------------------------ */

@@ -183,6 +183,10 @@ def gap_dense_f32(x, w_nc, bias):
     return x.reshape(B, -1, C).mean(1) @ w_nc.t() + (bias if bias is not None else 0)
 
 
+def head_prob(z):
+    return torch.sigmoid(z) if z.shape[1] == 1 else torch.softmax(z, dim=-1)
+
+
 def cls_dense_f32(t, w_nc, bias):
     return t[:, 0] @ w_nc.t() + (bias if bias is not None else 0)
 
@@ -251,7 +255,7 @@ def patched(round_act=False):
     global ROUND_ACT
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops
-    names = ["conv2d", "dense", "dense_split", "gap_ln_dense_f32", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
+    names = ["conv2d", "dense", "dense_split", "gap_ln_dense_f32", "head_prob", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
              "scale_add_act", "mul", "radix_combine", "window_attention", "mhsa", "vit_tokens", "to_device_nhwc8"]
     saved = {n: getattr(ops, n) for n in names}
     old = ROUND_ACT

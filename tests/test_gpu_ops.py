@@ -493,6 +493,28 @@ def test_gap_ln_dense_head(B, HW, C, N, report):
     check(report, f"gap_ln_dense_f32 B{B} HW{HW} C{C} N{N}", got, ref, tol=1e-5)
 
 
+def test_score_kernels(report):
+    """vip_head_prob_f32 / vip_prob_to_score_f32 / vip_ensemble_mean_f32 vs main.py:109-114,142-143 restated with torch on the CPU."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    for N in (1, 2, 5):
+        z = torch.randn(300, N, generator=g) * 4
+        z[0, 0] = 60.0                                   # saturated logits stay finite
+        z[1, 0] = -60.0
+        p = ops.head_prob(z.cuda())
+        ref = torch.sigmoid(z) if N == 1 else torch.softmax(z, dim=-1)
+        check(report, f"head_prob N{N}", p, ref, tol=2e-6)
+        sc = ops.binary_score(p)
+        check(report, f"binary_score N{N}", sc, ref[:, 0] if N == 1 else 1.0 - ref[:, 0], tol=2e-6)
+    rows = torch.rand(7, 1001, generator=g)
+    buf = torch.zeros(7, 1024, device="cuda")
+    buf[:, :1001] = rows.cuda()
+    check(report, "ensemble_mean (strided rows)", ops.ensemble_mean(buf[:, :1001]), rows.mean(0), tol=1e-6)
+    out = torch.empty(3, 300, device="cuda")
+    ops.binary_score(torch.rand(300, 1, generator=g).cuda(), out=out[1])       # a row of the members x images matrix
+    torch.cuda.synchronize()
+
+
 def test_scale_add_act_two_outputs(report):
     ops = _ops()
     g = torch.Generator().manual_seed(11)

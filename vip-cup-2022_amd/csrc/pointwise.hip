@@ -583,3 +583,64 @@ extern "C" int vip_mul_f16(const void* a, const void* b, void* y, long rows, int
                        (const f16*)b + b_off, (f16*)y + y_off, total8, C / 8, lda, ldb, ldy);
     return vip_launch_status("vip_mul_f16");
 }
+
+// ---------------------------------------------------------------------------------------------
+// scores: what main.py does with a model's logits (:109-114) and with the members' scores (:142-143)
+// ---------------------------------------------------------------------------------------------
+namespace {
+// one thread per image; N (classes) is 1 or a handful
+__global__ __launch_bounds__(256) void head_prob_kernel(const float* __restrict__ z, float* __restrict__ p, float* __restrict__ score,
+                                                        int B, int N) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* zb = z + (long)b * N;
+    if (N == 1) {
+        const float v = 1.f / (1.f + __expf(-zb[0]));
+        if (p) p[b] = v;
+        if (score) score[b] = v;
+        return;
+    }
+    float m = zb[0];
+    for (int n = 1; n < N; ++n) m = fmaxf(m, zb[n]);
+    float sum = 0.f;
+    for (int n = 0; n < N; ++n) sum += __expf(zb[n] - m);
+    const float inv = 1.f / sum;
+    if (p)
+        for (int n = 0; n < N; ++n) p[(long)b * N + n] = __expf(zb[n] - m) * inv;
+    if (score) score[b] = 1.f - __expf(zb[0] - m) * inv;        // multi-class -> binary: 1 - p(class 0)
+}
+
+__global__ __launch_bounds__(256) void prob_to_score_kernel(const float* __restrict__ p, float* __restrict__ score, int B, int N) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) score[b] = N == 1 ? p[b] : 1.f - p[(long)b * N];
+}
+
+__global__ __launch_bounds__(256) void ensemble_mean_kernel(const float* __restrict__ s, float* __restrict__ out, int M, int n, long ld) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc += s[(long)m * ld + i];
+    out[i] = acc / (float)M;
+}
+}  // namespace
+
+extern "C" int vip_head_prob_f32(const float* logits, float* prob, float* score, int B, int N, void* stream) {
+    VIP_REQUIRE(logits && (prob || score), VIP_ERR_BAD_ARG, "vip_head_prob_f32: null pointer");
+    VIP_REQUIRE(B > 0 && N > 0, VIP_ERR_BAD_ARG, "vip_head_prob_f32: non-positive dimension");
+    hipLaunchKernelGGL(head_prob_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, prob, score, B, N);
+    return vip_launch_status("vip_head_prob_f32");
+}
+
+extern "C" int vip_prob_to_score_f32(const float* prob, float* score, int B, int N, void* stream) {
+    VIP_REQUIRE(prob && score, VIP_ERR_BAD_ARG, "vip_prob_to_score_f32: null pointer");
+    VIP_REQUIRE(B > 0 && N > 0, VIP_ERR_BAD_ARG, "vip_prob_to_score_f32: non-positive dimension");
+    hipLaunchKernelGGL(prob_to_score_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, prob, score, B, N);
+    return vip_launch_status("vip_prob_to_score_f32");
+}
+
+extern "C" int vip_ensemble_mean_f32(const float* scores, float* mean, int M, int n, long ld, void* stream) {
+    VIP_REQUIRE(scores && mean, VIP_ERR_BAD_ARG, "vip_ensemble_mean_f32: null pointer");
+    VIP_REQUIRE(M > 0 && n > 0 && ld >= n, VIP_ERR_BAD_ARG, "vip_ensemble_mean_f32: bad dimension");
+    hipLaunchKernelGGL(ensemble_mean_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores, mean, M, n, ld);
+    return vip_launch_status("vip_ensemble_mean_f32");
+}

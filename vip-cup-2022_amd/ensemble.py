@@ -326,11 +326,12 @@ def _score_batch(staged, members, flags: Optional[np.ndarray] = None) -> torch.T
         if hw not in cache:
             cache[hw] = batch.resized(hw, hw)
     def one_pass(inputs):
-        rows = []
-        for p in _MEMBER_STREAMS.predict_all(members, inputs):   # [n, C] fp32 each
-            p = (1.0 - p[:, 0]) if p.shape[1] > 1 else p[:, 0]   # main.py:113-114
-            rows.append(p.float())
-        return torch.stack(rows, 0)
+        from . import ops
+        preds = _MEMBER_STREAMS.predict_all(members, inputs)     # [n, C] fp32 each
+        rows = torch.empty((len(preds), preds[0].shape[0]), dtype=torch.float32, device=preds[0].device)
+        for m, p in enumerate(preds):
+            ops.binary_score(p, out=rows[m])                     # main.py:113-114
+        return rows
 
     if flags is None:
         return one_pass(cache)

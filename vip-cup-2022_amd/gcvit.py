@@ -209,7 +209,7 @@ class GCViT:
 
     def predict(self, x):
         z = self.logits(x)
-        return torch.sigmoid(z) if self.classes == 1 else torch.softmax(z, dim=-1)
+        return ops.head_prob(z)
 
 
 def GCViTTiny(params, classes=1, device="cuda"):

@@ -65,7 +65,7 @@ class _Base:
 
     def predict(self, x):
         z = self.logits(x)
-        return torch.sigmoid(z) if self.classes == 1 else torch.softmax(z, dim=-1)
+        return ops.head_prob(z)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -523,6 +523,37 @@ def gap_ln_dense_f32(x, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w_n
     return out
 
 
+def head_prob(z: torch.Tensor) -> torch.Tensor:
+    """fp32 logits ``[B, N]`` -> what ``model.predict`` returns: sigmoid for one class, softmax otherwise (fp32 ``[B, N]``)."""
+    assert z.dtype == torch.float32 and z.is_cuda and z.dim() == 2 and z.is_contiguous()
+    out = torch.empty_like(z)
+    st = _abi.lib().vip_head_prob_f32(_p(z), _p(out), None, z.shape[0], z.shape[1], _stream())
+    _abi.check(st, "vip_head_prob_f32")
+    return out
+
+
+def binary_score(p: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """probabilities ``[n, C]`` (a model's ``predict``) -> the per-image score of main.py:113-114 (``p`` for one class, ``1 - p[:, 0]``
+    otherwise), fp32 ``[n]``; ``out``: a row of the members x images score matrix."""
+    n, Cc = p.shape
+    if out is None:
+        out = torch.empty((n,), dtype=torch.float32, device=p.device)
+    assert out.dtype == torch.float32 and out.shape == (n,) and out.is_contiguous()
+    pf = p if (p.dtype == torch.float32 and p.is_contiguous()) else p.float().contiguous()
+    st = _abi.lib().vip_prob_to_score_f32(_p(pf), _p(out), n, Cc, _stream())
+    _abi.check(st, "vip_prob_to_score_f32")
+    return out
+
+
+def ensemble_mean(scores: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[M, n]`` member scores -> ``[n]`` ensemble mean (main.py:142-143)."""
+    assert scores.dtype == torch.float32 and scores.is_cuda and scores.dim() == 2 and scores.stride(1) == 1
+    out = torch.empty((scores.shape[1],), dtype=torch.float32, device=scores.device)
+    st = _abi.lib().vip_ensemble_mean_f32(_p(scores), _p(out), scores.shape[0], scores.shape[1], scores.stride(0), _stream())
+    _abi.check(st, "vip_ensemble_mean_f32")
+    return out
+
+
 def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
     """act(x * scale[b,c] + residual); with ``act2`` returns ``(y, act2(y))`` from one launch.
     ``scale`` is [B, C] fp16 or a split gate [B, 2, C] (planes summed in fp32)."""

@@ -151,7 +151,7 @@ class ResNetRS:
     def predict(self, x: torch.Tensor) -> torch.Tensor:
         """``model.predict`` equivalent (main.py:109): sigmoid for 1 class, softmax otherwise (host, B x classes floats)."""
         z = self.logits(x)
-        return torch.sigmoid(z) if self.classes == 1 else torch.softmax(z, dim=-1)
+        return ops.head_prob(z)
 
 
 def ResNetRS50(params, classes=1, first_strides=2, device="cuda"):

@@ -127,7 +127,7 @@ class ViT:
 
     def predict(self, x):
         z = self.logits(x)
-        return torch.sigmoid(z) if self.cfg.nb_classes == 1 else torch.softmax(z, dim=-1)
+        return ops.head_prob(z)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -233,4 +233,4 @@ class ConvNeXt:
 
     def predict(self, x):
         z = self.logits(x)
-        return torch.sigmoid(z) if self.cfg.nb_classes == 1 else torch.softmax(z, dim=-1)
+        return ops.head_prob(z)

@@ -132,10 +132,10 @@ class Workload:
                 if hw not in cache:
                     cache[hw] = batch.resized(hw, hw)        # cast + bicubic + /255 (dataset.py:31-38)
             for m, p in zip(midx, streams.predict_all(sub, cache)):
-                local[(s, m)] = ((1.0 - p[:, 0]) if p.shape[1] > 1 else p[:, 0]).float()      # main.py:113-114
+                local[(s, m)] = ops.binary_score(p)                                      # main.py:113-114
         full = ensemble.gather_plan_scores(self.plan, self.rank, n_images, local, dist if self.world > 1 else None,
                                            torch.device("cuda"))
-        self.scores = full.mean(0)                           # ensemble mean per image (main.py:142-143)
+        self.scores = ops.ensemble_mean(full)                # ensemble mean per image (main.py:142-143)
         return self.scores
 
     def close(self):
