@@ -311,6 +311,20 @@ int vip_tta_augment_f16(const void* x, void* y, const int32_t* flags, int B, int
                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * MBConv front half in one launch:  z = act_d( dwconv_kxk,stride( zero_pad( act_e( conv1x1(x; we) + be ) ) ) + bd ).
+ * Replaces the expand Conv2D(1x1)+BN+swish and the DepthwiseConv2D(k, strides)+BN+swish of kecam's inverted residual block
+ * (efficientnet_v2.py:63-66,85-90): the expanded tensor stays in LDS.  Same rounding points as vip_conv2d_nhwc_f16 /
+ * vip_conv2d_hilo_nhwc_f16 followed by vip_dwconv2d_nhwc_f16 (the expanded activations are rounded to fp16 before the filter).
+ * x f16 [B,H,W,Cin]; we f16 [Ce][ldw] (+ optional we_lo, the low halves of two-term weights); be, bd f32 [Ce] or NULL;
+ * wd f32 [k][k][Ce]; z f16 [B,Ho,Wo,Ce]; (pt, pl) = zero padding of the depthwise input.  vip_mbconv_expand_dw_supported:
+ * Cin % 8 == 0, Cin <= 128, Ce % 32 == 0, k in {3, 5}, stride in {1, 2}.
+ * ------------------------------------------------------------------------------------------ */
+int vip_mbconv_expand_dw_supported(int Cin, int Ce, int k, int stride);
+int vip_mbconv_expand_dw_f16(const void* x, const void* we, const void* we_lo, const float* be, const float* wd, const float* bd,
+                             void* z, int B, int H, int W, int Cin, int Ce, int ldw, int k, int stride, int pt, int pl, int Ho,
+                             int Wo, int act_e, int act_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Scores.
  * vip_head_prob_f32: what `model.predict` applies to the logits - sigmoid for one class, softmax otherwise (the Dense(classes,
  *   activation=...) heads of resnet_rs_model.py:474-476, gcvit models/gcvit.py:109-113, tfimm / kecam classifiers) -> prob [B][N]

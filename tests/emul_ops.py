@@ -146,6 +146,10 @@ def dwconv2d(x, w_khwc, bias, k, stride=1, pad=(0, 0, 0, 0), act=None):
     return _r(R.act(R.dwconv2d(x, w_khwc.float()[..., None], bias, stride, pad), _an(act)), "dw")
 
 
+def mbconv_expand_dw(x, cw, w_khwc, dw_bias, k, stride, pad, act=None):
+    return dwconv2d(conv2d(x, cw, act=act), w_khwc, dw_bias, k, stride, pad, act=act)
+
+
 def layernorm(x, gamma, beta, eps):
     return _r(R.layernorm(x, gamma, beta, eps), "ln")
 
@@ -255,7 +259,7 @@ def patched(round_act=False):
     global ROUND_ACT
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops
-    names = ["conv2d", "dense", "dense_split", "gap_ln_dense_f32", "head_prob", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
+    names = ["conv2d", "dense", "dense_split", "gap_ln_dense_f32", "head_prob", "mbconv_expand_dw", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
              "scale_add_act", "mul", "radix_combine", "window_attention", "mhsa", "vit_tokens", "to_device_nhwc8"]
     saved = {n: getattr(ops, n) for n in names}
     old = ROUND_ACT

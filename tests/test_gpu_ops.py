@@ -493,6 +493,50 @@ def test_gap_ln_dense_head(B, HW, C, N, report):
     check(report, f"gap_ln_dense_f32 B{B} HW{HW} C{C} N{N}", got, ref, tol=1e-5)
 
 
+# MBConv expand 1x1 + depthwise in one launch: every (k, stride), the three slab widths (64 / 48 / 32), K below / at a k-step boundary,
+# two-term expand weights, tile tails, maps smaller than a tile, TF SAME padding on even and odd sizes (asymmetric for stride 2)
+@pytest.mark.parametrize("k,s,Cin,Ce,H,W,B,hilo", [(3, 1, 32, 192, 13, 11, 2, True), (3, 2, 24, 144, 20, 20, 2, True),
+                                                   (5, 1, 56, 336, 9, 17, 3, False), (5, 2, 32, 192, 15, 15, 2, True),
+                                                   (3, 2, 56, 336, 7, 7, 3, False), (5, 1, 112, 672, 6, 6, 2, False),
+                                                   (3, 1, 128, 416, 10, 10, 1, False), (3, 1, 8, 32, 3, 3, 5, False)])
+def test_mbconv_expand_dw(k, s, Cin, Ce, H, W, B, hilo, report):
+    """vip_mbconv_expand_dw_f16 vs conv1x1 -> silu -> zero-pad -> depthwise -> silu of the oracle (kecam efficientnet_v2.py:63-90),
+    and vs the two-launch path of the product (same rounding points: agreement to an fp16 ulp of the output)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(k * 100 + s * 10 + Cin)
+    x = h(torch.randn(B, H, W, Cin, generator=g))
+    we = torch.randn(1, 1, Cin, Ce, generator=g) / math.sqrt(Cin)
+    be = torch.randn(Ce, generator=g) * 0.2
+    wd = torch.randn(k, k, Ce, 1, generator=g) / k
+    bd = torch.randn(Ce, generator=g) * 0.1
+    pt, pb = ((k - 1) // 2, k // 2) if s == 1 else same_pad_tf(H, k, s)
+    pl, pr = ((k - 1) // 2, k // 2) if s == 1 else same_pad_tf(W, k, s)
+    pad = (pt, pb, pl, pr)
+    hid = h(R.act(R.conv2d(x, we, be), "silu"))                      # the expanded activations are fp16 in both paths
+    ref = R.act(R.dwconv2d(hid, wd, bd, s, pad), "silu")
+    cw = ops.make_conv_weight(we, be, hilo=hilo)
+    assert (cw.w_lo is not None) == hilo
+    wdd, bdd = wd[..., 0].contiguous().cuda(), bd.cuda()
+    two = ops.mbconv_expand_dw(dev(x), cw, wdd, bdd, k, s, pad, act="silu")        # default: conv2d + dwconv2d
+    os.environ["VIP_MBCONV_FUSED"] = "1"
+    try:
+        got = ops.mbconv_expand_dw(dev(x), cw, wdd, bdd, k, s, pad, act="silu")
+    finally:
+        del os.environ["VIP_MBCONV_FUSED"]
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape == two.shape
+    check(report, f"mbconv_expand_dw k{k} s{s} Cin{Cin} Ce{Ce} {H}x{W} hilo={hilo}", got, ref, tol=3e-3)
+    d = (got.float() - two.float()).abs().max().item()
+    report(f"[ops] mbconv_expand_dw vs conv2d + dwconv2d: max |diff| {d:.2e}")
+    assert d <= 4e-3 * ref.abs().max().item()
+
+
+def same_pad_tf(size, k, s):
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return total // 2, total - total // 2
+
+
 def test_score_kernels(report):
     """vip_head_prob_f32 / vip_prob_to_score_f32 / vip_ensemble_mean_f32 vs main.py:109-114,142-143 restated with torch on the CPU."""
     ops = _ops()

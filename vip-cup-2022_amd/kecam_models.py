@@ -317,8 +317,11 @@ class EfficientNet(_Base):
                 else:
                     y = ops.conv2d(y, blk["out"], stride=s, pad=pad, act=act, residual=inp if blk["shortcut"] else None)
             else:
-                h = ops.conv2d(y, blk["exp"], act=act) if blk["exp"] is not None else y
-                h = ops.dwconv2d(h, blk["dw"][0], blk["dw"][1], k, s, self._pad(h.shape[1:3], k, s), act=act)
+                pad = self._pad(y.shape[1:3], k, s)
+                if blk["exp"] is not None:                           # expand 1x1 + depthwise: one launch where the C ABI takes the shape
+                    h = ops.mbconv_expand_dw(y, blk["exp"], blk["dw"][0], blk["dw"][1], k, s, pad, act=act)
+                else:
+                    h = ops.dwconv2d(y, blk["dw"][0], blk["dw"][1], k, s, pad, act=act)
                 a = ops.se_gate(h, blk["se"][0], blk["se"][1], act, "sigmoid") if blk["se"] is not None else None
                 y = ops.conv2d(h, blk["out"], residual=inp if blk["shortcut"] else None, gate=a)   # h * se folded in
             last_of_stage = i + 1 == len(self.blocks) or self.blocks[i + 1]["stage"] != blk["stage"]

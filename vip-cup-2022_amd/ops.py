@@ -4,6 +4,7 @@ PyTorch is used for device memory and streams only.  Activations are fp16, conti
 (``[B,H,W,C]``) or row-major ``[rows, C]``.  Every function launches on torch's current stream.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -447,6 +448,35 @@ def dwconv2d(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stri
     st = _abi.lib().vip_dwconv2d_nhwc_f16(_p(x), _p(w_khwc), _p(bias), _p(out), B, H, W, Cc, k, stride, pt, pl,
                                           Ho, Wo, _act(act), _stream())
     _abi.check(st, "vip_dwconv2d_nhwc_f16")
+    return out
+
+
+def mbconv_expand_dw(x, cw: ConvWeight, w_khwc: torch.Tensor, dw_bias: Optional[torch.Tensor], k: int, stride: int, pad, act=None):
+    """``act(dwconv(act(conv1x1(x, cw)), w_khwc) + dw_bias)`` - the expand convolution and the depthwise convolution of an MBConv
+    block - as ``conv2d`` then ``dwconv2d``, or with ``VIP_MBCONV_FUSED=1`` in ONE launch where the C ABI takes the shape (the
+    expanded tensor stays in LDS): the same fp16 values either way up to fp32 summation order.  The fused kernel is opt-in because
+    it measured 0.4-0.8x the speed of the two launches (``tools/bench_mbconv.py``, ``profiles/r02_mbconv_fused_vs_two_launches.log``):
+    the two HBM-bound kernels hide their swish evaluations (exp + rcp each) behind memory, the fused one is VALU-bound on them plus
+    the halo recompute.  Calibration / exact-weight passes always run the two launches."""
+    B, H, W, ldx = x.shape
+    ok = (not _UNFUSED and os.environ.get("VIP_MBCONV_FUSED", "0") == "1" and cw.kh == cw.kw == 1 and cw.groups == 1 and ldx == cw.cin
+          and w_khwc.shape == (k, k, cw.cout) and _abi.lib().vip_mbconv_expand_dw_supported(cw.cin, cw.cout, k, stride))
+    if not ok:
+        return dwconv2d(conv2d(x, cw, act=act), w_khwc, dw_bias, k, stride, pad, act=act)
+    _chk16(x, "mbconv_expand_dw.x")
+    pt, pb, pl, pr = pad
+    Ho = (H + pt + pb - k) // stride + 1
+    Wo = (W + pl + pr - k) // stride + 1
+    out = torch.empty((B, Ho, Wo, cw.cout), dtype=torch.float16, device=x.device)
+    tok = None
+    if _PROF is not None:
+        tok = _PROF.start("mbconv_expand_dw_kernel", 2.0 * B * (H * W * cw.cin + Ho * Wo * k * k) * cw.cout,
+                          2.0 * (x.numel() + out.numel() + cw.w.numel()), f"{H}x{W} Cin={cw.cin} Ce={cw.cout} k{k} s{stride}")
+    st = _abi.lib().vip_mbconv_expand_dw_f16(_p(x), _p(cw.w), _p(cw.w_lo), _p(cw.bias), _p(w_khwc), _p(dw_bias), _p(out), B, H, W,
+                                             cw.cin, cw.cout, cw.ldw, k, stride, pt, pl, Ho, Wo, _act(act), _act(act), _stream())
+    if tok is not None:
+        _PROF.stop(tok)
+    _abi.check(st, "vip_mbconv_expand_dw_f16")
     return out
 
 
