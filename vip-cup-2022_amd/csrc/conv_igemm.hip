@@ -517,9 +517,11 @@ int launch_pw_k(const ConvArgs& a, int mode, hipStream_t s) {
 // arithmetic from the VALU (offsets here are linear in k) and gives each wave a 64 x 128 accumulator tile.
 // Short-K variant of the kernel below: the activation fragments are fetched global -> VGPR directly (no LDS image,
 // one barrier per chunk).  2-5 % faster than the LDS-staged form for K < 768, 5-10 % slower beyond (bench_gemm.py).
-template <int NG, bool GATED>
+// PT = 16-pixel tiles per wave: 4 (256-pixel block tile) by default; 2 / 1 for layers whose 256-pixel grid would leave most of the
+// chip idle (7x7 and 13x13 maps with narrow outputs: 98 workgroups for M = 12 544, N = 208) - more, smaller workgroups.
+template <int NG, bool GATED, int PT = 4>
 __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode) {
-    constexpr int PT = 4, NB = 64 * NG, ROWB = 160;          // LDS row: 64 halfs + 32 B pad (stride = 32 mod 64: launch_pw)
+    constexpr int NB = 64 * NG, ROWB = 160;                  // LDS row: 64 halfs + 32 B pad (stride = 32 mod 64: launch_pw)
     constexpr int STAGE = NB * ROWB;
     constexpr int W_IT = NB / 32;                            // 16-byte weight chunks staged per thread per k-chunk
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -934,14 +936,25 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
     }
 }
 
+template <int NG, int PT>
+void launch_pwk_direct_pt(ConvArgs& a, int mode, hipStream_t s) {
+    a.m_blocks = (a.M + 64 * PT - 1) / (64 * PT);
+    const dim3 grid((unsigned)(a.m_blocks * a.n_blocks));
+    if (a.gate) hipLaunchKernelGGL((pwk_direct_kernel<NG, true, PT>), grid, dim3(256), 0, s, a, mode);
+    else hipLaunchKernelGGL((pwk_direct_kernel<NG, false, PT>), grid, dim3(256), 0, s, a, mode);
+}
+
 template <int NG>
 int launch_pwk_direct(const ConvArgs& a0, int mode, hipStream_t s) {
     ConvArgs a = a0;
-    a.m_blocks = (a.M + 255) / 256;
     a.n_blocks = (a.Cout_g + 64 * NG - 1) / (64 * NG);
-    const dim3 grid((unsigned)(a.m_blocks * a.n_blocks));
-    if (a.gate) hipLaunchKernelGGL((pwk_direct_kernel<NG, true>), grid, dim3(256), 0, s, a, mode);
-    else hipLaunchKernelGGL((pwk_direct_kernel<NG, false>), grid, dim3(256), 0, s, a, mode);
+    // fewer 256-pixel workgroups than CUs (7x7 / 13x13 maps with narrow outputs): 64-pixel tiles instead - measured 48 -> 29 us on
+    // M = 12 544, N = 208, K = 1 248 (98 -> 392 workgroups), 35 -> 28 us on 43 264 x 128 x 768; 128-pixel tiles in the band up to
+    // 2 x CUs measured no gain and are not instantiated (tools/bench_pwk_fill.py, profiles/r02_pwk_small_tiles_ab.log)
+    static const int fill = getenv("VIP_PWK_FILL") ? atoi(getenv("VIP_PWK_FILL")) : 256;
+    const long wg256 = (long)((a.M + 255) / 256) * a.n_blocks;
+    if (wg256 < fill) launch_pwk_direct_pt<NG, 1>(a, mode, s);
+    else launch_pwk_direct_pt<NG, 4>(a, mode, s);
     return vip_launch_status("vip_conv2d_nhwc_f16(pwk-direct)");
 }
 
