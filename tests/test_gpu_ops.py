@@ -244,7 +244,8 @@ def test_dense_pointwise_modes(M, K, N, mode, report):
 # tiles, short and long K loops, every epilogue family; the dispatcher must really pick it
 @pytest.mark.parametrize("mode", ["gelu", "res", "none"])
 @pytest.mark.parametrize("M,K,N", [(33017, 384, 512), (20000, 1536, 768), (16640, 768, 3072), (65536 + 5, 448, 256), (8500, 3072, 1024)])
-def test_dense_gemm8p(M, K, N, mode, report):
+def test_dense_gemm8p(M, K, N, mode, report, monkeypatch):
+    monkeypatch.setenv("VIP_G8P_MINK", "256")          # the product default is 1024 (three-stream step); read per call
     ops = _ops()
     from vipcup_amd import _abi
     g = torch.Generator().manual_seed(M + K + N)

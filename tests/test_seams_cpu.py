@@ -113,10 +113,10 @@ def test_workspace_query_and_kernel_name_are_exported():
     lib = _abi.lib()
     assert lib.vip_workspace_bytes(4, (C.c_int64 * 1)(129792), 1) == 129792       # JPEG planes: one byte per coefficient
     assert lib.vip_workspace_bytes(0, None, 0) == 0
-    d = _abi.ConvDesc(B=256, H=25, W=25, Cin=512, Cout=1024, kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Ho=25, Wo=25, groups=1, ldx=512,
-                      cin_off=0, ldy=1024, cout_off=0, ldr=0, res_off=0, ldw=512, act_pre=1, act_post=0)
+    d = _abi.ConvDesc(B=256, H=25, W=25, Cin=1024, Cout=1024, kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Ho=25, Wo=25, groups=1, ldx=1024,
+                      cin_off=0, ldy=1024, cout_off=0, ldr=0, res_off=0, ldw=1024, act_pre=1, act_post=0)
     buf = C.create_string_buffer(64)
-    assert lib.vip_conv2d_kernel_name(C.byref(d), 0, 0, 0, buf, 64) == 0 and buf.value == b"gemm8p_kernel"   # K 512, N 1024: the LDS-DMA kernel
+    assert lib.vip_conv2d_kernel_name(C.byref(d), 0, 0, 0, buf, 64) == 0 and buf.value == b"gemm8p_kernel"   # K 1024, N 1024: the LDS-DMA kernel
     d.Cout, d.ldy = 320, 320
     assert lib.vip_conv2d_kernel_name(C.byref(d), 0, 0, 0, buf, 64) == 0 and buf.value.startswith(b"pwk_")      # N % 256 != 0
     d.B = 4

@@ -1210,8 +1210,12 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
         }
         VIP_REQUIRE(!y_lo_off && !x_split, VIP_ERR_UNSUPPORTED, "vip_gemm_split_f16: at most 256 rows, N %% 4 == 0");
         if (mode >= 0 && (pw_mode & 1) && short_k && M >= 65536 && !gate) VIP_PICK("pw_gemm_kernel", launch_pw_k<4>(a, mode, s));
-        // deep K, wide N: the LDS-DMA kernel (gemm8p.hpp).  VIP_G8P_MINK: smallest K it takes (0 = never).
-        static const int g8_min_k = getenv("VIP_G8P_MINK") ? atoi(getenv("VIP_G8P_MINK")) : 256;
+        // deep K, wide N: the LDS-DMA kernel (gemm8p.hpp).  VIP_G8P_MINK: smallest K it takes (0 = never).  1024: in isolation it
+        // wins from K = 256 up (+6..+27 %), but it owns a CU (128 KB of LDS, 8 waves x 256 VGPRs, persistent) and the ensemble step
+        // runs three member streams - with the K = 256-768 layers on it the STEP was 1.5-2 % slower (58.2 ms vs 57.1-57.4,
+        // alternating runs on one box, profiles/r02_gemm8p_mink_streams_ab.log) and a single stream gained nothing either.
+        const char* g8_env = getenv("VIP_G8P_MINK");     // read per call: the kernel's own tests lower it
+        const int g8_min_k = g8_env ? atoi(g8_env) : 1024;
         if (mode >= 0 && g8_min_k > 0 && !gate && a.K >= g8_min_k && gemm8p_eligible(a) && cout_g % 256 == 0 &&
             (long)((M + 255) / 256) * (cout_g / 256) >= 128)
             VIP_PICK("gemm8p_kernel", launch_gemm8p(a, mode, s));
