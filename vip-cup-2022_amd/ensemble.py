@@ -191,21 +191,44 @@ def score_files(jpegs_for: Callable[[int, int], List[bytes]], n_images: int, mem
         from . import pipeline
         return pipeline.entropy_decode(raws, pinned=True)
 
-    # one batch of read-ahead: the host stage of batch i+1 runs while the GPU scores batch i (the reference gets the
-    # same overlap from tf.data's prefetch, dataset/dataset.py:101)
+    # read-ahead (the overlap the reference gets from tf.data's prefetch, dataset/dataset.py:101): while the GPU scores batch i the
+    # host stage of batch i+2 runs on a worker thread, and the DEVICE half of batch i+1 (H2D of the coefficients, IDCT, colour) is
+    # enqueued on the launching stream between the fork of the member streams and their join - that stream idles while the members
+    # run, so the work lands under them instead of at the head of the next batch (MemberStreams.predict_all(after_fork=...))
+    from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     chunks: Dict[Tuple[int, int], List[torch.Tensor]] = {}
     with ThreadPoolExecutor(max_workers=1) as pool:
-        nxt = pool.submit(host_stage, work[0]) if work else None
+        todo = iter(work)
+        futs: deque = deque()
+
+        def submit_next():
+            item = next(todo, None)
+            if item is not None:
+                futs.append(pool.submit(host_stage, item))
+
+        submit_next()
+        decoded = [None]
+
+        def after_fork():
+            if scorer is None and futs and decoded[0] is None:
+                from . import pipeline
+                st = futs.popleft().result()
+                submit_next()
+                decoded[0] = pipeline.decode_entropy(st)
+
         for i, (s, midx, b0, b1) in enumerate(work):
-            staged = nxt.result()
-            nxt = pool.submit(host_stage, work[i + 1]) if i + 1 < len(work) else None
+            if decoded[0] is not None:
+                staged, decoded[0] = decoded[0], None
+            else:
+                staged = futs.popleft().result()
+                submit_next()
             sub = [members[m] for m in midx]
             fl = None if flags_all is None else flags_all[:, b0:b1]
             if scorer is not None:
                 rows = scorer(staged, sub) if fl is None else scorer(staged, sub, fl)
             else:
-                rows = _score_batch(staged, sub, fl)
+                rows = _score_batch(staged, sub, fl, after_fork=after_fork)
             for j, m in enumerate(midx):
                 chunks.setdefault((s, m), []).append(rows[j])
     local = {k: torch.cat(v) for k, v in chunks.items()}
@@ -256,17 +279,26 @@ class MemberStreams:
         self._assign[tuple(spec.name for spec, _ in members)] = assign
         return out
 
-    def predict_all(self, members, inputs) -> list:
-        """inputs: {input_hw: tensor} produced on the current stream.  Returns member.predict() per member."""
+    def predict_all(self, members, inputs, after_fork=None) -> list:
+        """inputs: {input_hw: tensor} produced on the current stream.  Returns member.predict() per member.
+        ``after_fork()`` is called once the members are enqueued on their streams and BEFORE the current stream joins them: work it
+        enqueues on the current stream (the next batch's H2D + IDCT) runs under the members instead of in front of the next step."""
         if self.n <= 1 or len(members) <= 1:
-            return [model.predict(inputs[spec.input_hw]) for spec, model in members]
+            out = [model.predict(inputs[spec.input_hw]) for spec, model in members]
+            if after_fork is not None:
+                after_fork()
+            return out
         assign = self._assign.get(tuple(spec.name for spec, _ in members))
         if assign is None:
-            return self._calibrate(members, inputs)
+            out = self._calibrate(members, inputs)
+            if after_fork is not None:
+                after_fork()
+            return out
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
         out = [None] * len(members)
+        joins = []
         for st, idxs in zip(self.streams, assign):
             if not idxs:
                 continue
@@ -277,6 +309,10 @@ class MemberStreams:
                     out[i] = model.predict(inputs[spec.input_hw])
             done = torch.cuda.Event()
             done.record(st)
+            joins.append(done)
+        if after_fork is not None:
+            after_fork()
+        for done in joins:
             main.wait_event(done)
         return out
 
@@ -310,13 +346,18 @@ def default_streams() -> int:
 _MEMBER_STREAMS: Optional[MemberStreams] = None
 
 
-def _score_batch(staged, members, flags: Optional[np.ndarray] = None) -> torch.Tensor:
-    """``staged`` = ``pipeline.entropy_decode(raws)`` (or the raw JPEG byte strings).  Decode once -> per member: resize
+def _score_batch(staged, members, flags: Optional[np.ndarray] = None, after_fork=None) -> torch.Tensor:
+    """``staged`` = ``pipeline.entropy_decode(raws)`` (or the raw JPEG byte strings, or an already decoded batch).  ``after_fork``:
+    called once, between the fork and the join of the member streams (see ``MemberStreams.predict_all``).  Decode once -> per member: resize
     to its resolution, predict, multi->binary.  Returns [M, n] (device).
     ``flags`` bool [tta, n, 3] (hflip, vflip, gray): one pass per row over augmented copies of the resized batch, mean
     over passes (the mean commutes with the multi->binary map 1 - p0)."""
     from . import pipeline
-    batch = pipeline.decode_entropy(staged) if isinstance(staged, tuple) else pipeline.decode_jpegs(staged)
+    if isinstance(staged, pipeline.DecodedBatch):
+        batch = staged
+    else:
+        batch = pipeline.decode_entropy(staged) if isinstance(staged, tuple) else pipeline.decode_jpegs(staged)
+    hook = [after_fork]
     global _MEMBER_STREAMS
     if _MEMBER_STREAMS is None:
         _MEMBER_STREAMS = MemberStreams(default_streams())
@@ -327,7 +368,8 @@ def _score_batch(staged, members, flags: Optional[np.ndarray] = None) -> torch.T
             cache[hw] = batch.resized(hw, hw)
     def one_pass(inputs):
         from . import ops
-        preds = _MEMBER_STREAMS.predict_all(members, inputs)     # [n, C] fp32 each
+        preds = _MEMBER_STREAMS.predict_all(members, inputs, after_fork=hook[0])     # [n, C] fp32 each
+        hook[0] = None
         rows = torch.empty((len(preds), preds[0].shape[0]), dtype=torch.float32, device=preds[0].device)
         for m, p in enumerate(preds):
             ops.binary_score(p, out=rows[m])                     # main.py:113-114

@@ -10,6 +10,7 @@ on a worker thread as in ensemble.score_files) -> H2D -> GPU dequant / IDCT / up
 member resolution -> forward of the members this rank owns -> ONE all-gather of the score payloads -> ensemble mean.
 ``resident=True`` is the round-1 variant: the step starts from decoded RGB u8 pixels already in HBM.
 """
+import os
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Sequence
 
@@ -96,6 +97,8 @@ class Workload:
         self._serial = ensemble.MemberStreams(1)
         self._pool = ThreadPoolExecutor(max_workers=1)
         self._ahead = None
+        self._dev_ahead = None
+        self._prefetch = os.environ.get("VIP_INPUT_PREFETCH", "1") != "0"
         self._resident_batch = None
         if resident:
             self._resident_batch = pipeline.decode_jpegs(self.jpegs)
@@ -111,9 +114,29 @@ class Workload:
             return self._resident_batch
         if self._ahead is None:
             self._ahead = self._pool.submit(self._host_stage)
+        if not self._prefetch:                                   # device half at the head of the step
+            staged = self._ahead.result()
+            self._ahead = self._pool.submit(self._host_stage)
+            return pipeline.decode_entropy(staged)
+        if self._dev_ahead is None:                              # first call: nothing was prefetched yet
+            self._decode_next()
+        batch, self._dev_ahead = self._dev_ahead, None
+        return batch
+
+    def _decode_next(self):
+        """Device half of the NEXT batch (H2D of the coefficients, IDCT, upsampling, colour), enqueued on the launching stream between
+        the fork of the member streams and their join: that stream is idle while the members run, so the work lands under them
+        instead of at the head of the next step; the batch after that is in the host Huffman stage on the read-ahead thread
+        (tf.data's prefetch, dataset/dataset.py:101).  No extra stream: a fifth stream (or a fourth member stream) made the step
+        3-7 ms SLOWER - HIP multiplexes streams onto 4 hardware queues and two busy streams then share one
+        (profiles/r02_input_prefetch_and_hw_queues_ab.log)."""
+        if self.resident or self._dev_ahead is not None:
+            return
+        if self._ahead is None:
+            self._ahead = self._pool.submit(self._host_stage)
         staged = self._ahead.result()
         self._ahead = self._pool.submit(self._host_stage)
-        return pipeline.decode_entropy(staged)
+        self._dev_ahead = pipeline.decode_entropy(staged)
 
     # ---- one step ----------------------------------------------------------------------------------------------------
     def step(self, dist=None, serial: bool = False):
@@ -131,7 +154,7 @@ class Workload:
                 hw = spec.input_hw
                 if hw not in cache:
                     cache[hw] = batch.resized(hw, hw)        # cast + bicubic + /255 (dataset.py:31-38)
-            for m, p in zip(midx, streams.predict_all(sub, cache)):
+            for m, p in zip(midx, streams.predict_all(sub, cache, after_fork=self._decode_next if self._prefetch else None)):
                 local[(s, m)] = ops.binary_score(p)                                      # main.py:113-114
         full = ensemble.gather_plan_scores(self.plan, self.rank, n_images, local, dist if self.world > 1 else None,
                                            torch.device("cuda"))
