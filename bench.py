@@ -126,12 +126,17 @@ def timed_steps(wl, dist, steps, warmup):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # pipelined steps (VIP_STEP_PIPELINE=0: join every step): step i is joined and scored after step i+1 has been forked; the step
+    # left in flight is flushed INSIDE the bracket it was forked in, so the timed region holds exactly `steps` forks and `steps` joins
+    pipe = os.environ.get("VIP_STEP_PIPELINE", "1") != "0"
     for _ in range(warmup):
-        wl.step(dist)
+        wl.step(dist, pipelined=pipe)
+    wl.flush(dist)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        wl.step(dist)
+        wl.step(dist, pipelined=pipe)
+    wl.flush(dist)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:

@@ -85,3 +85,12 @@ def test_workload_scores_match_oracle(name, report):
     # four members average their (uncorrelated) errors less than seven or eight do: 1.5e-3 for config 4, the north-star 1e-3 for config 5
     tol = P.TOL_ENSEMBLE_PROB if len(wl.members) >= 7 else 1.5 * P.TOL_ENSEMBLE_PROB
     assert d <= tol and d2 <= tol
+    # pipelined steps (what bench.py times): step i's scores come back from step i+1, the last from flush(); same images, same scores
+    assert wl.step(pipelined=True) is None
+    p1 = wl.step(pipelined=True).float().cpu().numpy().reshape(-1)
+    p2 = wl.flush().float().cpu().numpy().reshape(-1)
+    assert wl.flush() is not None                                # nothing in flight any more: the last scores again
+    dp = max(np.abs(p1 - got2).max(), np.abs(p2 - got2).max())
+    report(f"[{name}] pipelined steps vs joined steps: max|dp| {dp:.3e}")
+    assert dp <= 1e-6                                            # same kernels on the same inputs
+    wl.close()

@@ -279,21 +279,23 @@ class MemberStreams:
         self._assign[tuple(spec.name for spec, _ in members)] = assign
         return out
 
-    def predict_all(self, members, inputs, after_fork=None) -> list:
+    def predict_all(self, members, inputs, after_fork=None, defer_join: bool = False):
         """inputs: {input_hw: tensor} produced on the current stream.  Returns member.predict() per member.
         ``after_fork()`` is called once the members are enqueued on their streams and BEFORE the current stream joins them: work it
-        enqueues on the current stream (the next batch's H2D + IDCT) runs under the members instead of in front of the next step."""
+        enqueues on the current stream (the next batch's H2D + IDCT) runs under the members instead of in front of the next step.
+        ``defer_join``: return ``(predictions, join_events)`` without making the current stream wait - the caller joins later
+        (``MemberStreams.join``), so the next batch's members can start on the streams that finish first."""
         if self.n <= 1 or len(members) <= 1:
             out = [model.predict(inputs[spec.input_hw]) for spec, model in members]
             if after_fork is not None:
                 after_fork()
-            return out
+            return (out, []) if defer_join else out
         assign = self._assign.get(tuple(spec.name for spec, _ in members))
         if assign is None:
             out = self._calibrate(members, inputs)
             if after_fork is not None:
                 after_fork()
-            return out
+            return (out, []) if defer_join else out
         main = torch.cuda.current_stream()
         ready = torch.cuda.Event()
         ready.record(main)
@@ -312,9 +314,16 @@ class MemberStreams:
             joins.append(done)
         if after_fork is not None:
             after_fork()
+        if defer_join:
+            return out, joins
+        self.join(joins)
+        return out
+
+    @staticmethod
+    def join(joins):
+        main = torch.cuda.current_stream()
         for done in joins:
             main.wait_event(done)
-        return out
 
 
 def measure_costs(members, raws: Sequence[bytes], dist=None, rank: int = 0) -> List[float]:

@@ -98,6 +98,7 @@ class Workload:
         self._pool = ThreadPoolExecutor(max_workers=1)
         self._ahead = None
         self._dev_ahead = None
+        self._pending = None
         self._prefetch = os.environ.get("VIP_INPUT_PREFETCH", "1") != "0"
         self._resident_batch = None
         if resident:
@@ -139,12 +140,15 @@ class Workload:
         self._dev_ahead = pipeline.decode_entropy(staged)
 
     # ---- one step ----------------------------------------------------------------------------------------------------
-    def step(self, dist=None, serial: bool = False):
+    def step(self, dist=None, serial: bool = False, pipelined: bool = False):
+        """One pass of the hot path over one batch per image-shard.  Returns this step's ensemble scores - or, with ``pipelined``, the
+        PREVIOUS step's (None on the first call; ``flush()`` returns the last): the launching stream then does not join the member
+        streams before the next step is forked, so a stream that finishes early starts on the next batch instead of idling through the
+        tail of the slowest one (the inputs of the next batch are prepared under the members anyway, ``_decode_next``)."""
         if dist is None and self.world > 1:
             raise RuntimeError("Workload.step: world > 1 needs the process group")
         streams = self._serial if serial else self.member_streams
-        n_images = self.batch * self.world
-        local = {}
+        units = []
         for s in sorted(self.plan.units[self.rank]):
             midx = self.plan.units[self.rank][s]
             sub = [self.models[m] for m in midx]
@@ -154,7 +158,24 @@ class Workload:
                 hw = spec.input_hw
                 if hw not in cache:
                     cache[hw] = batch.resized(hw, hw)        # cast + bicubic + /255 (dataset.py:31-38)
-            for m, p in zip(midx, streams.predict_all(sub, cache, after_fork=self._decode_next if self._prefetch else None)):
+            preds, joins = streams.predict_all(sub, cache, after_fork=self._decode_next if self._prefetch else None, defer_join=True)
+            units.append((s, midx, preds, joins, cache))     # the inputs stay referenced until the unit is joined
+        if not pipelined:
+            return self._finish(units, dist)
+        prev, self._pending = self._pending, units
+        return self._finish(prev, dist) if prev is not None else None
+
+    def flush(self, dist=None):
+        """join and score the step a pipelined ``step`` left in flight"""
+        prev, self._pending = self._pending, None
+        return self._finish(prev, dist) if prev is not None else self.scores
+
+    def _finish(self, units, dist):
+        n_images = self.batch * self.world
+        local = {}
+        for s, midx, preds, joins, _cache in units:
+            ensemble.MemberStreams.join(joins)
+            for m, p in zip(midx, preds):
                 local[(s, m)] = ops.binary_score(p)                                      # main.py:113-114
         full = ensemble.gather_plan_scores(self.plan, self.rank, n_images, local, dist if self.world > 1 else None,
                                            torch.device("cuda"))
@@ -162,6 +183,7 @@ class Workload:
         return self.scores
 
     def close(self):
+        self._pending = None
         if self._ahead is not None:
             self._ahead.result()
             self._ahead = None
