@@ -9,7 +9,8 @@ Same contract: the input CSV has a ``filename`` column with paths relative to th
 it only in memory).  The ensemble manifest is ``ckpts/ckpts.json`` ([name, [H,W], idx],
 main.py:171-198); members whose graph is not built yet are reported and skipped only under ``--allow-missing``.
 
-Checkpoints: ``<script dir>/ckpts/<name>/ckpt/*.npz`` (a flat dict of Keras-named arrays, one file per fold).
+Checkpoints: ``<script dir>/ckpts/<name>/ckpt/*.h5`` (Keras weight / model files, as in the reference) or ``*.npz`` (a flat dict of
+Keras-named arrays), one file per fold.
 The reference ships none (README.md:13) and raises when a directory is empty (main.py:194); so does this CLI,
 unless ``--synthetic`` asks for the seeded synthetic checkpoints.
 """
@@ -91,14 +92,14 @@ def main(argv=None):
     for mi, (name, dim, idx, key) in enumerate(manifest):
         spec = zoo.MEMBERS[key]
         assert [spec.input_hw, spec.input_hw] == list(dim), (name, dim)
-        ckpts = sorted(glob(os.path.join(HERE, "ckpts", name, "ckpt", "*.npz")))
+        ckpts = sorted(glob(os.path.join(HERE, "ckpts", name, "ckpt", "*.npz")) + glob(os.path.join(HERE, "ckpts", name, "ckpt", "*.h5")))
         if mi not in mine:
             if not ckpts and not a.synthetic:
                 raise ValueError(f"no checkpoints under ckpts/{name}/ckpt (pass --synthetic for seeded synthetic weights)")
             members.append((spec, None))
             continue
         if ckpts:
-            folds = [zoo.construct(spec, {k: torch.from_numpy(v) for k, v in np.load(c).items()}) for c in ckpts]
+            folds = [zoo.construct(spec, zoo.read_checkpoint(c)) for c in ckpts]
         elif a.synthetic:
             folds = [zoo.build_member(key)[1]]
         else:

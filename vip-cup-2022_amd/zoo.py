@@ -201,9 +201,22 @@ def _fold_mean_cls():
 FoldMean = _fold_mean_cls()
 
 
+def read_checkpoint(path: str):
+    """One fold checkpoint -> ``{Keras variable name: torch tensor}``.  ``*.npz``: a flat dict of Keras-named arrays; ``*.h5`` /
+    ``*.hdf5``: a Keras weight or model file (what the reference's ``ckpt/*.h5`` are, main.py:101-107,186-194), read by the pure-Python
+    HDF5 reader ``h5lite`` - variable names with the ``:0`` suffix dropped, i.e. the same keys the ``.npz`` form uses."""
+    if path.endswith((".h5", ".hdf5")):
+        from . import h5lite
+        arrays = h5lite.load_keras_weights(path)
+    else:
+        arrays = dict(np.load(path).items())
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in arrays.items()}
+
+
 def load_model(path: str, compile: bool = False):
-    """Counterpart of ``tf.keras.models.load_model(path, compile=False)`` (main.py:107) for this build's checkpoint format:
-    ``path`` = ``.../ckpts/<member directory>/ckpt/<fold>.npz`` (a flat dict of Keras-named arrays).  The member graph is picked from
+    """Counterpart of ``tf.keras.models.load_model(path, compile=False)`` (main.py:107) for this build's checkpoint formats:
+    ``path`` = ``.../ckpts/<member directory>/ckpt/<fold>.npz`` (a flat dict of Keras-named arrays) or ``<fold>.h5`` (a Keras weight /
+    model file, ``read_checkpoint``).  The member graph is picked from
     the directory name exactly as the reference picks its batch size from it (main.py:70-71,85); the returned object has the
     ``predict(dataset, steps, verbose) -> np.ndarray [n, C]`` of a Keras model."""
     model_name = os.path.basename(os.path.dirname(os.path.dirname(os.path.abspath(path))))
@@ -211,4 +224,4 @@ def load_model(path: str, compile: bool = False):
     if key is None:
         raise ValueError(f"load_model: no graph for checkpoint directory {model_name!r}")
     spec = MEMBERS[key]
-    return construct(spec, {k: torch.from_numpy(v) for k, v in np.load(path).items()})
+    return construct(spec, read_checkpoint(path))
