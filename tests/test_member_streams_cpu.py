@@ -1,0 +1,130 @@
+"""The fork / join contract of ensemble.MemberStreams.predict_all on fake streams (no GPU): where after_fork runs, what defer_join
+returns, that every member is predicted exactly once on the stream its group was packed onto, and that the launching stream waits
+for every side stream - the scheduling the bench step and the CLI loop rely on (input prefetch between fork and join)."""
+import contextlib
+
+import pytest
+import torch
+
+import vipcup_amd  # noqa: F401
+from vipcup_amd import ensemble
+
+
+class FakeEvent:
+    def __init__(self, log, enable_timing=False):
+        self.log, self.stream = log, None
+
+    def record(self, stream=None):
+        self.stream = stream if stream is not None else FakeCuda.current
+        self.log.append(("record", self.stream.name))
+
+    def synchronize(self):
+        pass
+
+    def elapsed_time(self, other):
+        return FakeCuda.costs.pop(0)
+
+
+class FakeStream:
+    n = 0
+
+    def __init__(self, log, name=None):
+        self.log = log
+        if name is None:
+            FakeStream.n += 1
+            name = f"side{FakeStream.n}"
+        self.name = name
+
+    def wait_event(self, ev):
+        self.log.append(("wait", self.name, ev.stream.name))
+
+
+class FakeCuda:
+    current = None
+    costs = []
+
+
+class Member:
+    def __init__(self, name, log):
+        self.name, self.log = name, log
+
+    def predict(self, x):
+        self.log.append(("predict", self.name, FakeCuda.current.name))
+        return (self.name, x)
+
+
+class Spec:
+    def __init__(self, name, hw):
+        self.name, self.input_hw = name, hw
+
+
+@pytest.fixture
+def fake_cuda(monkeypatch):
+    log = []
+    FakeStream.n = 0
+    main = FakeStream(log, "main")
+    FakeCuda.current = main
+
+    @contextlib.contextmanager
+    def stream_ctx(st):
+        old, FakeCuda.current = FakeCuda.current, st
+        try:
+            yield
+        finally:
+            FakeCuda.current = old
+
+    monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: FakeStream(log))
+    monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: FakeEvent(log, *a, **k))
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: FakeCuda.current)
+    monkeypatch.setattr(torch.cuda, "stream", stream_ctx)
+    return log
+
+
+def test_fork_after_fork_join_order(fake_cuda):
+    log = fake_cuda
+    members = [(Spec(n, hw), Member(n, log)) for n, hw in [("a", 224), ("b", 200), ("c", 224), ("d", 384), ("e", 200)]]
+    inputs = {224: "x224", 200: "x200", 384: "x384"}
+    ms = ensemble.MemberStreams(3)
+    FakeCuda.costs = [9.0, 5.0, 4.0, 3.0, 1.0]                      # the one-off serial timing pass
+    hook = []
+    first = ms.predict_all(members, inputs, after_fork=lambda: hook.append(len(log)))
+    assert [p[0] for p in first] == ["a", "b", "c", "d", "e"] and len(hook) == 1
+    assert all(e[2] == "main" for e in log if e[0] == "predict")    # calibration pass: serial, on the launching stream
+    assert ms.cost_ms == {"a": 9.0, "b": 5.0, "c": 4.0, "d": 3.0, "e": 1.0}
+
+    del log[:]
+    out = ms.predict_all(members, inputs, after_fork=lambda: log.append(("after_fork",)))
+    assert out == [(n, inputs[hw]) for n, hw in [("a", 224), ("b", 200), ("c", 224), ("d", 384), ("e", 200)]]
+    on = {e[1]: e[2] for e in log if e[0] == "predict"}
+    assert sorted(on) == ["a", "b", "c", "d", "e"] and "main" not in on.values()
+    # longest-first packing of 9, 5, 4, 3, 1 onto three streams: a | b | c, then d (3) joins the lightest (c: 4 -> 7), e (1) joins b (5 -> 6)
+    groups = {}
+    for m, st in on.items():
+        groups.setdefault(st, []).append(m)
+    assert sorted(sorted(g) for g in groups.values()) == [["a"], ["b", "e"], ["c", "d"]]
+    i_fork = log.index(("after_fork",))
+    assert all(log.index(e) < i_fork for e in log if e[0] == "predict")                      # everything is enqueued before the hook
+    joins = [e for e in log if e[0] == "wait" and e[1] == "main"]
+    assert len(joins) == 3 and all(log.index(e) > i_fork for e in joins)                       # the launching stream joins AFTER the hook
+    assert {e[2] for e in joins} == set(groups)                                                # ... every side stream
+    assert [e for e in log if e[0] == "wait" and e[1] != "main"] == [("wait", s, "main") for s in ("side1", "side2", "side3")]
+
+    del log[:]
+    out2, events = ms.predict_all(members, inputs, defer_join=True)
+    assert out2 == out and len(events) == 3
+    assert not [e for e in log if e[0] == "wait" and e[1] == "main"]                           # nobody waited yet
+    ensemble.MemberStreams.join(events)
+    assert len([e for e in log if e[0] == "wait" and e[1] == "main"]) == 3
+
+
+def test_single_stream_and_single_member(fake_cuda):
+    log = fake_cuda
+    members = [(Spec("a", 224), Member("a", log)), (Spec("b", 224), Member("b", log))]
+    called = []
+    ms = ensemble.MemberStreams(1)
+    out, ev = ms.predict_all(members, {224: "x"}, after_fork=lambda: called.append(1), defer_join=True)
+    assert [o[0] for o in out] == ["a", "b"] and ev == [] and called == [1]
+    assert not [e for e in log if e[0] in ("wait", "record")]
+    ms3 = ensemble.MemberStreams(3)
+    out = ms3.predict_all(members[:1], {224: "x"}, after_fork=lambda: called.append(2))
+    assert out == [("a", "x")] and called == [1, 2]
