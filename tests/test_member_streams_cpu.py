@@ -128,3 +128,65 @@ def test_single_stream_and_single_member(fake_cuda):
     ms3 = ensemble.MemberStreams(3)
     out = ms3.predict_all(members[:1], {224: "x"}, after_fork=lambda: called.append(2))
     assert out == [("a", "x")] and called == [1, 2]
+
+
+def test_workload_pipelined_steps_and_input_prefetch(fake_cuda, monkeypatch):
+    """workloads.Workload on fakes: a pipelined step returns the previous step's scores (flush() the last), the next batch's device
+    decode is enqueued between the fork and the join of the current one, and every batch is decoded exactly once."""
+    import numpy as np
+    from vipcup_amd import ops, pipeline, workloads
+    log = fake_cuda
+    decoded = []
+
+    class Batch:
+        def __init__(self, k):
+            self.k = k
+
+        def resized(self, h, w):
+            return torch.full((4, 1), float(self.k))
+
+    def fake_entropy(jpegs, pinned=False):
+        return ("staged", len(decoded))
+
+    def fake_decode(staged):
+        decoded.append(len(log))
+        log.append(("decode", len(decoded)))
+        return Batch(len(decoded))
+
+    monkeypatch.setattr(pipeline, "entropy_decode", fake_entropy)
+    monkeypatch.setattr(pipeline, "decode_entropy", fake_decode)
+    monkeypatch.setattr(ops, "binary_score", lambda p, out=None: p[:, 0].float())
+    monkeypatch.setattr(ops, "ensemble_mean", lambda full: full.mean(0))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+
+    class Model:
+        def __init__(self, name, gain):
+            self.name, self.gain = name, gain
+
+        def predict(self, x):
+            log.append(("predict", self.name, FakeCuda.current.name))
+            return x * self.gain
+
+    models = [(Spec("a", 224), Model("a", 1.0)), (Spec("b", 200), Model("b", 3.0))]
+    class Reg:
+        gmac_per_image = 1.0
+    monkeypatch.setattr(workloads.zoo, "MEMBERS", {"a": Reg(), "b": Reg()})
+    monkeypatch.setattr(workloads, "MEMBER_MS_256", {"a": 2.0, "b": 1.0})
+    FakeCuda.costs = [2.0, 1.0]
+    wl = workloads.Workload("fake", ["a", "b"], batch=4, rank=0, world=1, jpegs=[b"x"] * 4, models=models)
+    monkeypatch.setattr(workloads.ensemble, "gather_plan_scores",
+                        lambda plan, rank, n, local, dist, dev: torch.stack([local[k] for k in sorted(local)]))
+    s1 = wl.step()                                                  # joined step (and the one-off calibration pass): batch 1
+    assert torch.equal(s1, torch.full((4,), 2.0))                   # mean of 1 * 1 and 1 * 3
+    assert [e for e in log if e[0] == "decode"] == [("decode", 1), ("decode", 2)]      # batch 2 was prefetched during step 1
+    del log[:]
+    assert wl.step(pipelined=True) is None                          # batch 2 forked, nothing to return yet
+    i_dec = log.index(("decode", 3))
+    assert all(log.index(e) < i_dec for e in log if e[0] == "predict")                  # the prefetch sits behind the fork ...
+    assert not [e for e in log if e[0] == "wait" and e[1] == "main"]                    # ... and nobody has joined
+    s2 = wl.step(pipelined=True)                                    # forks batch 3, joins and scores batch 2
+    assert torch.equal(s2, torch.full((4,), 4.0))
+    s3 = wl.flush()
+    assert torch.equal(s3, torch.full((4,), 6.0)) and torch.equal(wl.flush(), s3)
+    assert len(decoded) == 4                                        # batches 1-3 scored, batch 4 prefetched, none decoded twice
+    wl.close()
