@@ -177,3 +177,29 @@ def test_cli_two_ranks_share_the_card(tmp_path, shard, report):
     far = np.abs(a.ensemble_mean.values - 0.487) > 1e-3
     d1, d2 = pd.read_csv(tmp_path / "out1.csv"), pd.read_csv(tmp_path / "out2.csv")
     assert d1.filename.tolist() == d2.filename.tolist() and (d1.logit.values[far] == d2.logit.values[far]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists("/opt/conda/bin/python3.9"), reason="no interpreter with h5py in this image")
+def test_load_model_from_keras_h5(tmp_path, report):
+    """zoo.load_model on ckpts/<member directory>/ckpt/0.h5 - a Keras weight file written by h5py / libhdf5 from the member's variables -
+    gives the same predictions as the model built from the variables themselves (main.py:101-107 load path, .h5 form)."""
+    import subprocess
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import pipeline, zoo
+    key = "vit_tiny_patch16_224"
+    spec = zoo.MEMBERS[key]
+    params = zoo.build_params(key)
+    ckpt_dir = tmp_path / "ckpts" / spec.ckpt_name / "ckpt"
+    ckpt_dir.mkdir(parents=True)
+    npz, h5 = str(tmp_path / "p.npz"), str(ckpt_dir / "0.h5")
+    np.savez(npz, **{k: v.numpy() for k, v in params.items()})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["/opt/conda/bin/python3.9", os.path.join(root, "tools", "npz_to_keras_h5.py"), npz, h5], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    x = pipeline.decode_jpegs([synth_jpeg(40 + i) for i in range(4)]).resized(spec.input_hw, spec.input_hw)
+    want = zoo.construct(spec, params).predict(x)
+    got = zoo.load_model(h5).predict(x)
+    d = (got - want).abs().max().item()
+    report(f"[h5] load_model({spec.ckpt_name}/ckpt/0.h5): max |dp| vs the model built from the variables {d:.1e}")
+    assert d == 0.0

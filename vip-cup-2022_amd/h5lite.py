@@ -87,6 +87,8 @@ class Dataset:
         ver = r.u(off, 1)
         n_el = int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
         nbytes = n_el * self.dtype.itemsize
+        if n_el < 0 or nbytes > 64 * max(len(r.b), 1 << 20):     # deflate cannot expand by more: a damaged dataspace, not data
+            raise H5Error(f"{self.name}: shape {self.shape} is not plausible for a {len(r.b)}-byte file")
         if ver in (3, 4):           # version 4 (libver "latest") keeps the compact / contiguous forms; its chunk indices differ
             cls = r.u(off + 1, 1)
             if ver == 4 and cls == 2:
@@ -476,6 +478,17 @@ def _names(v) -> List[str]:
 
 
 def load_keras_weights(path: str) -> Dict[str, np.ndarray]:
+    """``_load_keras_weights`` with every failure mode of a damaged file (truncation, pointers into nowhere or in circles, bad deflate
+    streams, impossible shapes) turned into ``H5Error``: a corrupt checkpoint is reported, never half-read."""
+    try:
+        return _load_keras_weights(path)
+    except H5Error:
+        raise
+    except (IndexError, KeyError, ValueError, OverflowError, MemoryError, RecursionError, UnicodeDecodeError, zlib.error, struct.error) as e:
+        raise H5Error(f"{path}: damaged HDF5 file ({type(e).__name__}: {e})") from e
+
+
+def _load_keras_weights(path: str) -> Dict[str, np.ndarray]:
     """``model.save_weights('x.h5')`` / ``model.save('x.h5')`` -> ``{variable name without ':0': array}``, in Keras' own order
     (root attribute ``layer_names``, per-layer attribute ``weight_names``, both possibly split into ``...0, ...1`` chunks -
     keras/saving/hdf5_format.py ``save_attributes_to_hdf5_group``); a full-model file keeps the same tree under ``model_weights``.
