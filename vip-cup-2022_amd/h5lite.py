@@ -80,7 +80,7 @@ class Dataset:
         return self.read()
 
     def read(self) -> np.ndarray:
-        f, r = self.file, self.file.r
+        r = self.file.r
         if self._vlen:
             raise H5Unsupported(f"{self.name}: variable-length dataset")
         off, _ = self._layout
@@ -168,7 +168,7 @@ class Group:
                 if addr is not None:
                     self._links[k] = addr
             elif t == 0x2:     # link info: dense storage if the fractal heap address is defined
-                ver, fl = f.r.u(off, 1), f.r.u(off + 1, 1)
+                fl = f.r.u(off + 1, 1)
                 p = off + 2 + (8 if fl & 1 else 0)
                 if f.r.offs(p) != UNDEF:
                     raise H5Unsupported(f"{name}: dense link storage (fractal heap)")
@@ -330,7 +330,7 @@ class File(Group):
 
     def _link(self, off: int):
         r = self.r
-        ver, fl = r.u(off, 1), r.u(off + 1, 1)
+        fl = r.u(off + 1, 1)
         p = off + 2
         ltype = 0
         if fl & 0x08:
@@ -367,7 +367,7 @@ class File(Group):
     # ---- messages -------------------------------------------------------------------------------------------------
     def _dataspace(self, off: int) -> Tuple[int, ...]:
         r = self.r
-        ver, rank, fl = r.u(off, 1), r.u(off + 1, 1), r.u(off + 2, 1)
+        ver, rank = r.u(off, 1), r.u(off + 1, 1)
         if ver == 1:
             p = off + 8
         elif ver == 2:
