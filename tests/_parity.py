@@ -31,6 +31,12 @@ def decode_pixels(raws):
     return [np.asarray(Image.open(io.BytesIO(r)).convert("RGB")) for r in raws]
 
 
+def e2e_image_ids(n: int):
+    """seeds of the synthetic JPEG set shared by the CLI test and the workload tests (one oracle pass per member and session):
+    n - 1 images of 200x200 and one 256x192 (the resize branch), no duplicates"""
+    return list(range(100, 100 + n - 1)) + [149 if n <= 50 else 49]
+
+
 def oracle_logits(key: str, set_name: str, raws) -> np.ndarray:
     """fp32 oracle logits of member `key` on the JPEG byte strings `raws` (cached per (member, set_name))."""
     import vipcup_amd  # noqa: F401
@@ -71,7 +77,7 @@ def sigmoid(z):
 
 
 def real_photo_tiles():
-    """>= 12 JPEG byte strings that are NOT from tools/make_synth: 200x200 tiles of the three photographs the reference embeds
+    """12 JPEG byte strings that are NOT from tools/make_synth: 200x200 tiles of the three photographs the reference embeds
     (tests/golden/ref_*.jpg, 512x512), re-encoded at quality 75 / 90, 4:2:0 / 4:4:4."""
     import os
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -79,7 +85,7 @@ def real_photo_tiles():
     k = 0
     for name in ("ref_cat.jpg", "ref_dog.jpg", "ref_dog_cat.jpg"):
         img = Image.open(os.path.join(here, name)).convert("RGB")
-        for (x0, y0) in ((20, 30), (290, 40), (60, 300), (300, 290), (150, 160)):
+        for (x0, y0) in ((20, 30), (290, 40), (60, 300), (300, 290)):
             buf = io.BytesIO()
             img.crop((x0, y0, x0 + 200, y0 + 200)).save(buf, format="JPEG", quality=(75, 90)[k % 2], subsampling=(2, 0)[(k // 2) % 2])
             raws.append(buf.getvalue())

@@ -16,6 +16,7 @@ from oracle import ops_ref as R  # noqa: E402
 from tools.make_synth import synth_jpeg  # noqa: E402
 
 N_IMG = int(os.environ.get("VIP_E2E_N", "16"))   # 16 in the suite; larger samples on demand (VIP_E2E_N=128)
+from tests import _parity as P  # noqa: E402
 from tests._parity import MEMBER_CEILING, TOL_ENSEMBLE_PROB, TOL_NORTH_STAR  # noqa: E402  (what the bounds mean: tests/_parity.py)
 
 
@@ -27,7 +28,7 @@ def _logit(p):
 def test_main_cli_matches_oracle(tmp_path, report):
     import vipcup_amd  # noqa: F401
     from vipcup_amd import main as cli, zoo
-    idx = list(range(100, 100 + N_IMG - 1)) + [149 if N_IMG <= 50 else 49]   # includes a 256x192 image (resize branch), no duplicates
+    idx = P.e2e_image_ids(N_IMG)                                             # includes a 256x192 image (resize branch), no duplicates
     names = []
     for i in idx:
         n = f"img_{i:05d}.jpg"
@@ -41,17 +42,13 @@ def test_main_cli_matches_oracle(tmp_path, report):
     assert list(dec.columns) == ["filename", "logit"] and set(dec.logit.unique()) <= {0.0, 1.0}
     assert dec.filename.tolist() == sorted(names)
 
-    # oracle path
-    pix = [np.asarray(Image.open(io.BytesIO(synth_jpeg(i))).convert("RGB")) for i in idx]
+    # oracle path (one fp32 CPU pass per member and session: tests/_parity.py caches it for the workload tests on the same images)
+    raws = [synth_jpeg(i) for i in idx]
     probs = {}
     per_member = {}
     worst = 0.0
     for key in zoo.ENSEMBLE:
-        spec = zoo.MEMBERS[key]
-        x = torch.stack([R.decode_resize_normalize(p, spec.input_hw, spec.input_hw) for p in pix])
-        ref = importlib.import_module(f"oracle.{spec.oracle}")
-        with torch.no_grad():
-            z = ref.predict_logits(key, zoo.build_params(key), x).numpy()[:, 0]
+        z = P.oracle_logits(key, "e2e", raws)
         probs[key] = 1.0 / (1.0 + np.exp(-z))
         dz = np.abs(_logit(got[key].values) - z)
         worst = max(worst, dz.max())

@@ -25,7 +25,7 @@ def _members():
 
 def test_real_photo_tiles_match_oracle(report):
     """Off the calibration distribution: the bias calibration (ops.calibration) is fitted on a seeded batch of the synthetic family;
-    these 15 tiles are photographs.  Same bounds as on the synthetic set."""
+    these 12 tiles are photographs.  Same bounds as on the synthetic set."""
     raws = P.real_photo_tiles()
     assert len(raws) >= 12
     probs_g, probs_o, over = [], [], {}
