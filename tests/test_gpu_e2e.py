@@ -199,4 +199,4 @@ def test_load_model_from_keras_h5(tmp_path, report):
     got = zoo.load_model(h5).predict(x)
     d = (got - want).abs().max().item()
     report(f"[h5] load_model({spec.ckpt_name}/ckpt/0.h5): max |dp| vs the model built from the variables {d:.1e}")
-    assert d == 0.0
+    assert d <= 1e-6          # 0.0 when measured; both models are constructed (and bias-calibrated) separately
