@@ -114,3 +114,19 @@ def test_damaged_files_are_reported_not_misread(tmp_path):
         except h5lite.H5Error:
             bad += 1
     assert ok + bad == 300 and bad > 50
+
+
+def test_enclosing_model_scope_is_stripped():
+    """variables exported from an enclosing Keras model (one common leading scope) still fit the member graph"""
+    import torch
+    from vipcup_amd import zoo
+    key = "vit_tiny_patch16_224"
+    spec = zoo.MEMBERS[key]
+    params = zoo.build_params(key)
+    scoped = {"vit_tiny_patch16_224/" + k: v for k, v in params.items()}
+    got = zoo.match_variable_names(spec, scoped)
+    assert set(got) == set(params) and all(torch.equal(got[k], params[k]) for k in params)
+    assert zoo.match_variable_names(spec, params) is params                      # already fitting: untouched
+    odd = dict(scoped)
+    odd["other_scope/x"] = torch.zeros(1)
+    assert zoo.match_variable_names(spec, odd) is odd                            # no single common scope: left for the constructor to report

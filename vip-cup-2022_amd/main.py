@@ -99,7 +99,7 @@ def main(argv=None):
             members.append((spec, None))
             continue
         if ckpts:
-            folds = [zoo.construct(spec, zoo.read_checkpoint(c)) for c in ckpts]
+            folds = [zoo.construct(spec, zoo.match_variable_names(spec, zoo.read_checkpoint(c))) for c in ckpts]
         elif a.synthetic:
             folds = [zoo.build_member(key)[1]]
         else:

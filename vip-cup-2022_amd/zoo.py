@@ -213,6 +213,20 @@ def read_checkpoint(path: str):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in arrays.items()}
 
 
+def match_variable_names(spec: MemberSpec, params):
+    """A checkpoint exported from an enclosing Keras model carries that model's name in front of every variable
+    (``convnext_tiny/stem/0/kernel`` for ``stem/0/kernel``): when the keys do not fit the graph as they are but do once ONE common leading
+    scope is removed, remove it.  Anything else is left alone - the constructor then names the first missing variable."""
+    want = set(spec.synth(spec.seed))
+    if want <= set(params):
+        return params
+    keys = list(params)
+    head = keys[0].split("/", 1)[0] + "/" if keys and "/" in keys[0] else None
+    if head and all(k.startswith(head) for k in keys) and want <= {k[len(head):] for k in keys}:
+        return {k[len(head):]: v for k, v in params.items()}
+    return params
+
+
 def load_model(path: str, compile: bool = False):
     """Counterpart of ``tf.keras.models.load_model(path, compile=False)`` (main.py:107) for this build's checkpoint formats:
     ``path`` = ``.../ckpts/<member directory>/ckpt/<fold>.npz`` (a flat dict of Keras-named arrays) or ``<fold>.h5`` (a Keras weight /
@@ -224,4 +238,4 @@ def load_model(path: str, compile: bool = False):
     if key is None:
         raise ValueError(f"load_model: no graph for checkpoint directory {model_name!r}")
     spec = MEMBERS[key]
-    return construct(spec, read_checkpoint(path))
+    return construct(spec, match_variable_names(spec, read_checkpoint(path)))
