@@ -217,6 +217,8 @@ def match_variable_names(spec: MemberSpec, params):
     """A checkpoint exported from an enclosing Keras model carries that model's name in front of every variable
     (``convnext_tiny/stem/0/kernel`` for ``stem/0/kernel``): when the keys do not fit the graph as they are but do once ONE common leading
     scope is removed, remove it.  Anything else is left alone - the constructor then names the first missing variable."""
+    if f"{spec.head}/kernel" in params:          # the classifier is where the graph expects it: nothing to do (and no synthesis cost)
+        return params
     want = set(spec.synth(spec.seed))
     if want <= set(params):
         return params
