@@ -191,7 +191,8 @@ class Workload:
 
     def config(self):
         inp = ("decoded 200x200 RGB u8 resident in HBM" if self.resident else
-               "200x200 JPEG byte strings in host RAM -> host Huffman (pinned, 1 batch read-ahead) -> H2D -> GPU IDCT/colour")
+               "200x200 JPEG byte strings in host RAM -> host Huffman (pinned, read-ahead thread) -> H2D -> GPU IDCT/colour"
+               + (" (the next batch's, enqueued between the fork and the join of the member streams)" if self._prefetch else ""))
         par = {"images": f"image-parallel dp{self.world}", "members": f"member-parallel mp{self.world} (rank r owns members r mod N)",
                "hybrid": f"hybrid LPT over {len(self.members)}x{self.world} (member, image-shard) units"}[self.shard]
         return {"workload": self.name + ("-resident" if self.resident else ""), "members": self.members,
