@@ -59,12 +59,12 @@ def oracle_logits(key: str, set_name: str, raws) -> np.ndarray:
 _MODELS = {}
 
 
-def gpu_member(key: str):
-    """(spec, model) built once per session (construction includes the bias-calibration pass)"""
+def gpu_member(key: str, precision: str = "fast"):
+    """(spec, model) built once per session and precision mode (fast: construction includes the bias-calibration pass)"""
     from vipcup_amd import zoo
-    if key not in _MODELS:
-        _MODELS[key] = zoo.build_member(key)
-    return _MODELS[key]
+    if (key, precision) not in _MODELS:
+        _MODELS[(key, precision)] = zoo.build_member(key, precision=precision)
+    return _MODELS[(key, precision)]
 
 
 def logit(p):

@@ -1,0 +1,293 @@
+"""GPU parity of the STRICT precision path (fp32 storage, v_mfma_f32_32x32x2_f32, libm activations; csrc/strict_*.hip): every
+operator against the fp32 CPU oracle at fp32 round-off, and every ensemble member's CALIBRATED logit within BASELINE.json's
+1e-3 (the mode in which the stated tolerance holds member by member - the fp16 path sits at its storage floor, tests/_parity.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gcvit_ref  # noqa: E402
+from oracle import ops_ref as R  # noqa: E402
+from tests import _parity as P  # noqa: E402
+from tools.make_synth import synth_jpeg  # noqa: E402
+
+N_IMG = int(os.environ.get("VIP_E2E_N", "16"))   # as tests/test_gpu_e2e.py
+TOL_OP = 2e-5        # relative to the output scale: fp32 summation order over K <= 4608 terms, libm vs torch transcendental ulps
+
+
+def _ops():
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ops
+    return ops
+
+
+def dev(t):
+    return t.to(torch.float32).cuda().contiguous()
+
+
+def check(report, name, got, ref, tol=TOL_OP):
+    got = got.float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    report(f"[strict-ops] {name}: max_abs_err={err:.3e} ref_absmax={scale:.3e} rel={err / scale:.3e}")
+    assert torch.isfinite(got).all(), name
+    assert err <= tol * scale, f"{name}: err {err} > {tol}*{scale}"
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad(t,b,l,r), groups, act, residual
+    (2, 9, 9, 8, 32, 3, 2, (1, 1, 1, 1), 1, "relu", False),       # stem-like: Cin=8, K=72 (partial k chunk), 32-channel tile
+    (2, 12, 10, 32, 64, 3, 1, (1, 1, 1, 1), 1, "relu", False),    # 3x3 same, 64-channel tile
+    (3, 7, 7, 64, 256, 1, 1, (0, 0, 0, 0), 1, None, True),        # 1x1 + residual, 128-channel tile x 2
+    (2, 13, 13, 128, 128, 3, 2, (1, 1, 1, 1), 1, "silu", False),  # stride 2 odd size
+    (1, 20, 20, 24, 40, 3, 1, (1, 1, 1, 1), 1, "gelu", False),    # ragged channels (40 of a 64 tile), K = 216
+    (2, 8, 8, 128, 128, 3, 1, (1, 1, 1, 1), 2, "relu", False),    # grouped (NFNet / ResNeSt style)
+    (2, 10, 10, 16, 200, 4, 2, (0, 0, 0, 0), 1, None, False),     # 4x4/2 VALID patchify, Cout = 200 (128 + 72)
+    (2, 6, 6, 512, 72, 1, 1, (0, 0, 0, 0), 1, "sigmoid", False),  # deep K, narrow N
+    (1, 33, 31, 64, 64, 3, 1, (1, 1, 1, 1), 1, "relu", True),     # M tail (1023 pixels)
+    (2, 9, 9, 64, 64, 5, 1, (2, 2, 2, 2), 1, None, False),        # 5x5
+    (2, 9, 9, 96, 96, 2, 2, (0, 0, 0, 0), 1, None, False),        # 2x2/2 downsample (ConvNeXt)
+    (2, 9, 9, 32, 32, 3, 2, (0, 1, 0, 1), 1, "silu", False),      # TF SAME asymmetric pad (EffNetV1)
+    (256, 1, 1, 2048, 512, 1, 1, (0, 0, 0, 0), 1, "relu", False),  # squeeze-excite Dense: M = batch
+    (2, 16, 16, 12, 8, 1, 1, (0, 0, 0, 0), 1, None, False),       # Cin = 12 (K tail inside a float4 group of the chunk), Cout 8
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:9]))
+def test_conv2d_strict(case, report):
+    ops = _ops()
+    B, H, W, Cin, Cout, k, s, pad, groups, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case[:9]) % (2 ** 31))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(k, k, Cin // groups, Cout, generator=g) / math.sqrt(k * k * Cin / groups)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    ref = R.act(R.conv2d(x, w, bias, s, pad, groups), act)
+    res = None
+    if use_res:
+        res = torch.randn(*ref.shape, generator=g)
+        ref = ref + res
+    with ops.precision("strict"):
+        cw = ops.make_conv_weight(w, bias, groups=groups)
+    assert cw.strict and cw.w.dtype == torch.float32
+    got = ops.conv2d(dev(x), cw, stride=s, pad=pad, act=act, residual=None if res is None else dev(res))
+    torch.cuda.synchronize()
+    assert got.dtype == torch.float32
+    check(report, f"conv2d {case}", got, ref)
+
+
+def test_conv2d_strict_channel_slices_and_gate(report):
+    """cin_off / cout_off (concat-free splits and joins), act_post after the residual, and a squeeze-excite gate"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 11, 9, 96, generator=g)
+    w = torch.randn(1, 1, 32, 48, generator=g) / math.sqrt(32)
+    b = torch.randn(48, generator=g) * 0.1
+    res = torch.randn(2, 11, 9, 48, generator=g)
+    with ops.precision("strict"):
+        cw = ops.make_conv_weight(w, b)
+    out = torch.zeros((2, 11, 9, 112), dtype=torch.float32, device="cuda")
+    ops.conv2d(dev(x), cw, residual=dev(res), act_post="relu", out=out, cin_off=32, cout_off=64)
+    ref = torch.relu(R.conv2d(x[..., 32:64], w, b) + res)
+    check(report, "conv2d slices", out[..., 64:112], ref)
+    assert float(out[..., :64].abs().max()) == 0.0
+    gate = torch.rand(2, 32, generator=g)
+    x2 = torch.randn(2, 5, 5, 32, generator=g)
+    got = ops.conv2d(dev(x2), cw, gate=dev(gate))
+    check(report, "conv2d gate", got, R.conv2d(x2 * gate[:, None, None, :], w, b))
+
+
+def test_dense_mlp_se_strict(report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(3, 50, 96, generator=g)
+    k1, b1 = torch.randn(96, 384, generator=g) / math.sqrt(96), torch.randn(384, generator=g) * 0.1
+    k2, b2 = torch.randn(384, 96, generator=g) / math.sqrt(384), torch.randn(96, generator=g) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(96, generator=g), 0.1 * torch.randn(96, generator=g)
+    with ops.precision("strict"):
+        fc1, fc2 = ops.make_dense_weight(k1, b1), ops.make_dense_weight(k2, b2)
+    got = ops.mlp(dev(x), fc1, fc2, act="gelu", residual=dev(x), ln=(dev(gam), dev(bet), 1e-5))
+    ref = x + R.dense(R.act(R.dense(R.layernorm(x, gam, bet, 1e-5), k1, b1), "gelu"), k2, b2)
+    check(report, "mlp", got, ref)
+    xs = torch.randn(4, 7, 7, 96, generator=g)
+    s = ops.se_gate(dev(xs), fc1, fc2, "silu", "sigmoid")
+    assert s.shape == (4, 96) and s.dtype == torch.float32
+    sref = torch.sigmoid(R.dense(R.act(R.dense(xs.mean((1, 2)), k1, b1), "silu"), k2, b2))
+    check(report, "se_gate", s, sref)
+    y = ops.scale_add_act(dev(xs), s, dev(xs), "relu")
+    check(report, "scale_add_act", y, torch.relu(xs * sref[:, None, None, :] + xs))
+    y1, y2 = ops.scale_add_act(dev(xs), None, None, None, act2="silu")
+    check(report, "scale_add_act second output", y2, R.act(xs, "silu"))
+    assert torch.equal(y1.cpu(), xs)
+
+
+@pytest.mark.parametrize("k,s,pad,act", [(3, 1, (1, 1, 1, 1), "gelu"), (3, 2, (0, 1, 0, 1), "silu"), (5, 1, (2, 2, 2, 2), "silu"),
+                                         (5, 2, (1, 2, 1, 2), None), (7, 1, (3, 3, 3, 3), None)])
+def test_dwconv_strict(k, s, pad, act, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(k * 10 + s)
+    x = torch.randn(2, 15, 13, 40, generator=g)
+    w = torch.randn(k, k, 40, 1, generator=g) / k
+    b = torch.randn(40, generator=g) * 0.1
+    got = ops.dwconv2d(dev(x), ops.make_dw_weight(w), dev(b), k, s, pad, act=act)
+    check(report, f"dwconv k{k} s{s}", got, R.act(R.dwconv2d(x, w, b, s, pad), act))
+
+
+def test_norm_pool_heads_strict(report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    for C in (64, 96, 768, 1536):
+        x = torch.randn(37, C, generator=g) * 2 + 0.3
+        gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+        check(report, f"layernorm C={C}", ops.layernorm(dev(x), dev(gam), dev(bet), 1e-6), R.layernorm(x, gam, bet, 1e-6))
+    x = torch.randn(2, 13, 11, 24, generator=g)
+    check(report, "avgpool same", ops.pool2d(dev(x), 2, 2, (0, 1, 0, 1), ops.POOL_AVG_VALID), R.avgpool_same(x, 2, 2))
+    check(report, "avgpool full", ops.pool2d(dev(x), 3, 2, (1, 1, 1, 1), ops.POOL_AVG_FULL), R.avgpool_valid(x, 3, 2, (1, 1, 1, 1)))
+    check(report, "maxpool zero-pad", ops.pool2d(dev(x), 3, 2, (1, 1, 1, 1), ops.POOL_MAX_ZEROPAD), R.maxpool_valid(x, 3, 2, (1, 1, 1, 1)))
+    check(report, "zero-pad copy", ops.pool2d(dev(x), 1, 1, (0, 1, 1, 2), ops.POOL_MAX_ZEROPAD), R.zero_pad(x, (0, 1, 1, 2)))
+    check(report, "crop", ops.pool2d(dev(x), 1, 1, (0, 0, 0, 0), ops.POOL_MAX_ZEROPAD, out_hw=(9, 7)), x[:, :9, :7].contiguous())
+    check(report, "global_avgpool", ops.global_avgpool(dev(x), split=True), x.mean((1, 2)))
+    wn, bn = torch.randn(3, 24, generator=g), torch.randn(3, generator=g)
+    check(report, "gap_dense", ops.gap_dense_f32(dev(x), dev(wn), dev(bn)), x.mean((1, 2)) @ wn.t() + bn)
+    gam, bet = 1 + 0.1 * torch.randn(24, generator=g), 0.1 * torch.randn(24, generator=g)
+    check(report, "gap_ln_dense", ops.gap_ln_dense_f32(dev(x), dev(gam), dev(bet), 1e-6, dev(wn), dev(bn)),
+          R.layernorm(x.mean((1, 2)), gam, bet, 1e-6) @ wn.t() + bn)
+    t = torch.randn(3, 17, 24, generator=g)
+    check(report, "cls_dense", ops.cls_dense_f32(dev(t), dev(wn), dev(bn)), t[:, 0] @ wn.t() + bn)
+    cls, pos = torch.randn(24, generator=g), torch.randn(18, 24, generator=g)
+    check(report, "vit_tokens", ops.vit_tokens(dev(t), dev(cls), dev(pos)),
+          torch.cat([cls.expand(3, 1, 24), t], 1) + pos[None])
+    xr, sr = torch.randn(2, 5, 6, 32, generator=g), torch.rand(2, 32, generator=g)
+    check(report, "radix_combine", ops.radix_combine(dev(xr), dev(sr), 2),
+          xr[..., :16] * sr[:, None, None, :16] + xr[..., 16:] * sr[:, None, None, 16:])
+    a, b = torch.randn(2, 5, 48, generator=g), torch.randn(2, 5, 32, generator=g)
+    check(report, "mul", ops.mul(dev(a), dev(b), 16, 32, 8), a[..., 32:48] * b[..., 8:24])
+
+
+@pytest.mark.parametrize("ws,heads,nwin,glob", [(7, 2, (2, 3), False), (7, 4, (1, 2), True), (14, 8, (1, 1), False), (14, 8, (1, 1), True)])
+def test_window_attention_strict(ws, heads, nwin, glob, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(ws * 100 + heads + glob)
+    B, C, N = 2, heads * 32, ws * ws
+    Hp, Wp = nwin[0] * ws, nwin[1] * ws
+    nq = 2 if glob else 3
+    qkv = torch.randn(B, Hp, Wp, nq * C, generator=g)
+    qg = torch.randn(B, N, C, generator=g) if glob else None
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5
+    scale = 32 ** -0.5
+    got = ops.window_attention(dev(qkv), None if qg is None else dev(qg), dev(table), heads, ws, scale)
+    win = R.window_partition(qkv, ws).reshape(-1, N, nq, heads, 32).permute(2, 0, 3, 1, 4)      # [nq, B_, heads, N, hd]
+    if glob:
+        k, v = win[0], win[1]
+        q = torch.repeat_interleave(qg, win.shape[1] // B, dim=0).reshape(-1, N, heads, 32).permute(0, 2, 1, 3)
+    else:
+        q, k, v = win[0], win[1], win[2]
+    o = gcvit_ref.window_attention_core(q, k, v, table, ws, scale).permute(0, 2, 1, 3).reshape(-1, ws, ws, C)
+    ref = R.window_reverse(o, ws, Hp, Wp, C)
+    check(report, f"window_attention ws{ws} heads{heads} global={glob}", got, ref)
+
+
+def test_mhsa_strict(report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    B, N, heads = 3, 197, 3
+    D = heads * 64
+    qkv = torch.randn(B, N, 3 * D, generator=g)
+    got = ops.mhsa(dev(qkv), heads, 64 ** -0.5)
+    t = qkv.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    attn = torch.softmax((64 ** -0.5) * (t[0] @ t[1].transpose(-1, -2)), dim=-1)
+    ref = (attn @ t[2]).permute(0, 2, 1, 3).reshape(B, N, D)
+    check(report, "mhsa", got, ref)
+
+
+def test_resize_strict_matches_oracle_bitwise(report):
+    """the strict input: the fp32 values of cast -> bicubic -> /255 (dataset.py:31-38), not rounded to fp16"""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import pipeline
+    raws = [synth_jpeg(100), synth_jpeg(101)]          # 256x192 and 200x200
+    batch = pipeline.decode_jpegs(raws)
+    pix = P.decode_pixels(raws)
+    for hw in (200, 224):
+        got = batch.resized(hw, hw, dtype=torch.float32).cpu()
+        ref = torch.stack([R.decode_resize_normalize(p, hw, hw) for p in pix])
+        d = (got[..., :3] - ref).abs().max().item()
+        report(f"[strict-ops] resize {hw}: max|d| {d:.3e}")
+        assert d <= 1e-6 and float(got[..., 3:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# whole members: the CALIBRATED logit (amplifying synthetic heads, tests/gen_synth_heads.py) within the north-star 1e-3
+# ---------------------------------------------------------------------------------------------------------------------------------
+STRICT_MEMBERS = ["convnext_tiny_in22k", "resnest50", "gcvit_tiny", "efficientnet_v2t", "efficientnet_v1b4", "eca_nfnet_l0",
+                  "resnet_rs50", "vit_small_patch16_224", "vit_tiny_patch16_224"]
+_Z = {}
+
+
+def _strict_logits(key, raws, tag):
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import pipeline
+    if (key, tag) not in _Z:
+        spec, model = P.gpu_member(key, "strict")
+        assert model.precision == "strict"
+        x = pipeline.decode_jpegs(raws).resized(spec.input_hw, spec.input_hw, dtype=torch.float32)
+        _Z[(key, tag)] = model.logits(x)[:, 0].float().cpu().numpy()
+    return _Z[(key, tag)]
+
+
+@pytest.mark.parametrize("key", STRICT_MEMBERS)
+def test_member_logit_within_north_star(key, report):
+    n = N_IMG
+    raws = [synth_jpeg(i) for i in P.e2e_image_ids(n)]
+    z = P.oracle_logits(key, "e2e", raws)               # the CLI test's image set: one oracle pass per member and session
+    zg = _strict_logits(key, raws, "e2e")
+    dz = np.abs(zg - z)
+    report(f"[strict] {key:22s} {n} images: max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e} logit std {z.std():.2f}")
+    assert np.isfinite(zg).all()
+    assert dz.max() <= P.TOL_NORTH_STAR
+
+
+def test_ensemble_logit_within_north_star(report):
+    """logit(ensemble mean) - the north-star axis - for the 7 manifest members, config 5's 8 and config 4's 4, on the synthetic set
+    and on the photo tiles (off the synthetic distribution: nothing is calibrated in strict mode, so there is no distribution to be off)"""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import zoo
+    n = N_IMG
+    sets = {"e2e": [synth_jpeg(i) for i in P.e2e_image_ids(n)], "photo": P.real_photo_tiles()}
+    for tag, raws in sets.items():
+        for name, members in (("ensemble7", zoo.ENSEMBLE), ("ensemble8", zoo.ENSEMBLE8), ("ensemble4", zoo.ENSEMBLE4)):
+            po = np.mean([P.sigmoid(P.oracle_logits(k, "e2e" if tag == "e2e" else "photo_tiles", raws)) for k in members], 0)
+            pg = np.mean([P.sigmoid(_strict_logits(k, raws, tag)) for k in members], 0)
+            dl = np.abs(P.logit(pg) - P.logit(po)).max()
+            flips = int(((pg > 0.487) != (po > 0.487)).sum())
+            report(f"[strict] {name} on {tag}: max|d logit(mean)|={dl:.3e} max|dp|={np.abs(pg - po).max():.3e} decision flips {flips}")
+            assert dl <= P.TOL_NORTH_STAR and flips == 0
+        if tag == "photo":
+            for k in zoo.ENSEMBLE8:
+                z = P.oracle_logits(k, "photo_tiles", raws)
+                dz = np.abs(_strict_logits(k, raws, tag) - z)
+                report(f"[strict] photo {k:22s} max|dz|={dz.max():.3e} (absolute) z range [{z.min():+.2f},{z.max():+.2f}]")
+                assert dz.max() <= P.TOL_NORTH_STAR
+
+
+def test_member_inside_batch_256_strict(report):
+    """B = 256 (what bench.py's strict leg times): images 0-7 of the batch against the oracle, two members"""
+    for key in ("resnet_rs50", "efficientnet_v1b4"):
+        raws = [synth_jpeg(1000 + i) for i in range(256)]
+        z = P.oracle_logits(key, "b256_first8", raws[:8])
+        zg = _strict_logits(key, raws, "b256")
+        d = np.abs(zg[:8] - z).max()
+        report(f"[strict] {key:22s} images 0-7 in a 256-batch: max|dz| {d:.3e}")
+        assert np.isfinite(zg).all() and d <= P.TOL_NORTH_STAR
+
+
+def test_precision_mismatch_is_an_error():
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import _abi, pipeline
+    spec, model = P.gpu_member("vit_tiny_patch16_224", "strict")
+    x16 = pipeline.decode_jpegs([synth_jpeg(3)]).resized(224, 224)
+    with pytest.raises(_abi.VipError):
+        model.predict(x16)

@@ -142,7 +142,7 @@ def test_workload_pipelined_steps_and_input_prefetch(fake_cuda, monkeypatch):
         def __init__(self, k):
             self.k = k
 
-        def resized(self, h, w):
+        def resized(self, h, w, dtype=None):
             return torch.full((4, 1), float(self.k))
 
     def fake_entropy(jpegs, pinned=False):

@@ -49,7 +49,7 @@ def _worker(rank, world, port, mode, q):
         def __init__(self, k):
             self.k = k
 
-        def resized(self, h, w):
+        def resized(self, h, w, dtype=None):
             return torch.full((4, 1), float(self.k))
 
     def decode(staged):

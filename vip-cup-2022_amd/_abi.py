@@ -75,6 +75,21 @@ SIGNATURES = {
     "vip_resize_bicubic_norm_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "vip_tta_augment_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_vit_tokens_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    # STRICT precision path (fp32 storage, fp32 arithmetic): csrc/strict_conv.hip, csrc/strict_ops.hip
+    "vip_conv2d_nhwc_s32": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
+    "vip_dwconv2d_nhwc_s32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
+    "vip_layernorm_s32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "vip_pool2d_nhwc_s32": (_i, [_vp, _vp] + [_i] * 13 + [_vp]),
+    "vip_global_avgpool_s32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vip_scale_add_act_s32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vip_radix_combine_s32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vip_mul_s32": (_i, [_vp, _vp, _vp, C.c_long] + [_i] * 7 + [_vp]),
+    "vip_vit_tokens_s32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vip_gap_ln_dense_s32": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, C.c_long, _i, _vp]),
+    "vip_window_attn_fwd_s32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _vp]),
+    "vip_mhsa_fwd_s32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "vip_resize_bicubic_norm_s32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "vip_tta_augment_s32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_conv2d_kernel_name": (_i, [C.POINTER(ConvDesc), _i, _i, _i, C.c_char_p, _sz]),
     "vip_workspace_bytes": (_sz, [_i, C.POINTER(C.c_int64), _i]),
     "vip_microbench_copy": (_i, [_vp, _vp, _sz, _vp]),

@@ -107,6 +107,19 @@ __device__ __forceinline__ float vip_act(float v, int act) {
     }
 }
 
+// ---- STRICT path activations (strict_*.hip): libm-accurate exp / erf and true division instead of the fast path's
+// v_exp_f32 / v_rcp_f32 / polynomial erfc approximations (each ~1e-7..7e-7; harmless next to an fp16 output rounding, but the
+// strict path's budget is fp32 round-off).  Keras: "gelu" = 0.5 x (1 + erf(x / sqrt 2)), "swish" = x sigmoid(x).
+__device__ __forceinline__ float vip_act_strict(float v, int act) {
+    switch (act) {
+        case VIP_ACT_RELU: return v > 0.f ? v : 0.f;
+        case VIP_ACT_SILU: return v / (1.f + expf(-v));
+        case VIP_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+        case VIP_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
 union U4H8 {
     uint4 u;
     f16x8 h;

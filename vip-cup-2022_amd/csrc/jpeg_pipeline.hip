@@ -222,23 +222,25 @@ __device__ __forceinline__ Taps bicubic_taps(int out_loc, int in_size, float sca
     return t;
 }
 
+// T = f16 (fast path) or float (STRICT path: the fp32 values tf.image.resize / 255 produces, not rounded)
+template <typename T>
 __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restrict__ rgb, const int* __restrict__ sizes,
-                                                          const float* __restrict__ table, f16* __restrict__ out,
+                                                          const float* __restrict__ table, T* __restrict__ out,
                                                           int maxH, int maxW, int outH, int outW, int c_out) {
     const int n = blockIdx.z;
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
     const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (ox >= outW || oy >= outH) return;
     const int h = sizes[2 * n], w = sizes[2 * n + 1];
-    f16* o = out + (((long)n * outH + oy) * outW + ox) * c_out;
+    T* o = out + (((long)n * outH + oy) * outW + ox) * c_out;
     auto store = [&](const float (&res)[3]) {
-        if (c_out == 8) {          // one 16-byte store per pixel
+        if (c_out == 8 && sizeof(T) == 2) {          // one 16-byte store per pixel
             U4H8 v;
             v.u = make_uint4(0, 0, 0, 0);
             v.e[0] = (f16)res[0]; v.e[1] = (f16)res[1]; v.e[2] = (f16)res[2];
             *reinterpret_cast<uint4*>(o) = v.u;
         } else {
-            for (int c = 0; c < c_out; ++c) o[c] = (f16)(c < 3 ? res[c] : 0.f);
+            for (int c = 0; c < c_out; ++c) o[c] = (T)(c < 3 ? res[c] : 0.f);
         }
     };
     if (h == outH && w == outW) {
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
 }
 
 // TTA: flags bit0 hflip, bit1 vflip, bit2 gray (tf.image.rgb_to_grayscale weights 0.2989/0.5870/0.1140)
-__global__ __launch_bounds__(256) void tta_kernel(const f16* __restrict__ x, f16* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void tta_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                   const int* __restrict__ flags, int H, int W, int C) {
     const int b = blockIdx.z;
     const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -284,11 +287,11 @@ __global__ __launch_bounds__(256) void tta_kernel(const f16* __restrict__ x, f16
     const int f = flags[b];
     const int sx = (f & 1) ? W - 1 - ox : ox;
     const int sy = (f & 2) ? H - 1 - oy : oy;
-    const f16* s = x + (((long)b * H + sy) * W + sx) * C;
-    f16* o = y + (((long)b * H + oy) * W + ox) * C;
+    const T* s = x + (((long)b * H + sy) * W + sx) * C;
+    T* o = y + (((long)b * H + oy) * W + ox) * C;
     if (f & 4) {
         const float g = 0.2989f * (float)s[0] + 0.5870f * (float)s[1] + 0.1140f * (float)s[2];
-        o[0] = o[1] = o[2] = (f16)g;
+        o[0] = o[1] = o[2] = (T)g;
         for (int c = 3; c < C; ++c) o[c] = s[c];
     } else {
         for (int c = 0; c < C; ++c) o[c] = s[c];
@@ -330,9 +333,20 @@ extern "C" int vip_resize_bicubic_norm_f16(const uint8_t* rgb_u8, const int32_t*
     VIP_REQUIRE(rgb_u8 && sizes_hw && table && out, VIP_ERR_BAD_ARG, "vip_resize_bicubic_norm_f16: null pointer");
     VIP_REQUIRE(n > 0 && maxH > 0 && maxW > 0 && outH > 0 && outW > 0 && c_out >= 3, VIP_ERR_BAD_ARG,
                 "vip_resize_bicubic_norm_f16: bad size");
-    hipLaunchKernelGGL(resize_norm_kernel, dim3((outW + 63) / 64, (outH + 3) / 4, n), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(resize_norm_kernel<f16>, dim3((outW + 63) / 64, (outH + 3) / 4, n), dim3(256), 0, (hipStream_t)stream,
                        rgb_u8, sizes_hw, table, (f16*)out, maxH, maxW, outH, outW, c_out);
     return vip_launch_status("vip_resize_bicubic_norm_f16");
+}
+
+extern "C" int vip_resize_bicubic_norm_s32(const uint8_t* rgb_u8, const int32_t* sizes_hw, const float* table,
+                                           int n, int maxH, int maxW, float* out, int outH, int outW, int c_out,
+                                           void* stream) {
+    VIP_REQUIRE(rgb_u8 && sizes_hw && table && out, VIP_ERR_BAD_ARG, "vip_resize_bicubic_norm_s32: null pointer");
+    VIP_REQUIRE(n > 0 && maxH > 0 && maxW > 0 && outH > 0 && outW > 0 && c_out >= 3, VIP_ERR_BAD_ARG,
+                "vip_resize_bicubic_norm_s32: bad size");
+    hipLaunchKernelGGL(resize_norm_kernel<float>, dim3((outW + 63) / 64, (outH + 3) / 4, n), dim3(256), 0, (hipStream_t)stream,
+                       rgb_u8, sizes_hw, table, out, maxH, maxW, outH, outW, c_out);
+    return vip_launch_status("vip_resize_bicubic_norm_s32");
 }
 
 extern "C" int vip_tta_augment_f16(const void* x, void* y, const int32_t* flags, int B, int H, int W, int C,
@@ -340,7 +354,15 @@ extern "C" int vip_tta_augment_f16(const void* x, void* y, const int32_t* flags,
     VIP_REQUIRE(x && y && flags, VIP_ERR_BAD_ARG, "vip_tta_augment_f16: null pointer");
     VIP_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 3, VIP_ERR_BAD_ARG, "vip_tta_augment_f16: bad size");
     VIP_REQUIRE(x != y, VIP_ERR_BAD_ARG, "vip_tta_augment_f16: in-place flips are not supported");
-    hipLaunchKernelGGL(tta_kernel, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(tta_kernel<f16>, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(256), 0, (hipStream_t)stream,
                        (const f16*)x, (f16*)y, flags, H, W, C);
     return vip_launch_status("vip_tta_augment_f16");
+}
+
+extern "C" int vip_tta_augment_s32(const float* x, float* y, const int32_t* flags, int B, int H, int W, int C, void* stream) {
+    VIP_REQUIRE(x && y && flags, VIP_ERR_BAD_ARG, "vip_tta_augment_s32: null pointer");
+    VIP_REQUIRE(B > 0 && H > 0 && W > 0 && C >= 3, VIP_ERR_BAD_ARG, "vip_tta_augment_s32: bad size");
+    VIP_REQUIRE(x != y, VIP_ERR_BAD_ARG, "vip_tta_augment_s32: in-place flips are not supported");
+    hipLaunchKernelGGL(tta_kernel<float>, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, x, y, flags, H, W, C);
+    return vip_launch_status("vip_tta_augment_s32");
 }

@@ -151,13 +151,17 @@ def tta_flags(n_images: int, tta: int, seed: int = 0) -> np.ndarray:
     image is left alone (``random_float() > 0.80``), otherwise hflip / vflip with p = 0.5 each and gray with p = 0.3.
     TensorFlow's RNG stream cannot be reproduced, so the draws come from a seeded numpy generator; they are a function
     of (seed, pass, image index) only, so the scores do not depend on batch size or on how images are sharded."""
-    out = np.zeros((tta, n_images, 3), dtype=bool)
-    for t in range(tta):
-        u = np.random.default_rng([int(seed), t]).random((n_images, 4))
-        on = ~(u[:, 0] > 0.80)
-        out[t, :, 0] = on & (u[:, 1] < 0.5)
-        out[t, :, 1] = on & (u[:, 2] < 0.5)
-        out[t, :, 2] = on & (u[:, 3] < 0.3)
+    return np.stack([tta_flags_pass(n_images, t, seed) for t in range(tta)]) if tta > 0 else np.zeros((0, n_images, 3), dtype=bool)
+
+
+def tta_flags_pass(n_images: int, t: int, seed: int = 0) -> np.ndarray:
+    """the draws of pass ``t`` alone: bool ``[n_images, 3]`` (``tta_flags(n, T, seed)[t]`` for any T > t)"""
+    out = np.zeros((n_images, 3), dtype=bool)
+    u = np.random.default_rng([int(seed), int(t)]).random((n_images, 4))
+    on = ~(u[:, 0] > 0.80)
+    out[:, 0] = on & (u[:, 1] < 0.5)
+    out[:, 1] = on & (u[:, 2] < 0.5)
+    out[:, 2] = on & (u[:, 3] < 0.3)
     return out
 
 
@@ -243,6 +247,39 @@ def score_files(jpegs_for: Callable[[int, int], List[bytes]], n_images: int, mem
     return full.detach().float().cpu().numpy()
 
 
+def member_dtype(model) -> torch.dtype:
+    """activation dtype a member was built for: fp32 for ``precision == "strict"`` (zoo.construct), fp16 otherwise"""
+    return torch.float32 if getattr(model, "precision", "fast") == "strict" else torch.float16
+
+
+def input_key(spec, model):
+    """key of a member's input tensor in the ``inputs`` dictionaries below: one resize launch per (resolution, dtype)"""
+    return (spec.input_hw, member_dtype(model))
+
+
+def member_inputs(batch, members) -> Dict:
+    """``{input_key: tensor}``: the decoded batch resized (cast -> bicubic -> /255, dataset.py:31-38) once per distinct
+    (resolution, dtype) among ``members`` = [(spec, model)] (model None = not resident on this rank: skipped)."""
+    out: Dict = {}
+    for spec, model in members:
+        if model is None:
+            continue
+        k = input_key(spec, model)
+        if k not in out:
+            out[k] = batch.resized(spec.input_hw, spec.input_hw, dtype=k[1])
+    return out
+
+
+def _record_stream(t, stream):
+    if isinstance(t, torch.Tensor) and t.is_cuda:
+        t.record_stream(stream)
+
+
+def _input_for(inputs, spec, model):
+    k = input_key(spec, model)
+    return inputs[k] if k in inputs else inputs[spec.input_hw]      # plain {resolution: tensor} dictionaries are accepted too
+
+
 class MemberStreams:
     """Runs the (independent) ensemble members on several HIP streams.
 
@@ -264,7 +301,7 @@ class MemberStreams:
         for i, (spec, model) in enumerate(members):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out.append(model.predict(inputs[spec.input_hw]))
+            out.append(model.predict(_input_for(inputs, spec, model)))
             e1.record()
             e1.synchronize()
             cost.append(e0.elapsed_time(e1))
@@ -286,7 +323,7 @@ class MemberStreams:
         ``defer_join``: return ``(predictions, join_events)`` without making the current stream wait - the caller joins later
         (``MemberStreams.join``), so the next batch's members can start on the streams that finish first."""
         if self.n <= 1 or len(members) <= 1:
-            out = [model.predict(inputs[spec.input_hw]) for spec, model in members]
+            out = [model.predict(_input_for(inputs, spec, model)) for spec, model in members]
             if after_fork is not None:
                 after_fork()
             return (out, []) if defer_join else out
@@ -308,7 +345,14 @@ class MemberStreams:
             with torch.cuda.stream(st):
                 for i in idxs:
                     spec, model = members[i]
-                    out[i] = model.predict(inputs[spec.input_hw])
+                    x = _input_for(inputs, spec, model)
+                    # allocator hygiene across streams: the input was allocated on the launching stream and is read here, the
+                    # prediction is allocated here and read on the launching stream - tell the caching allocator, so that neither
+                    # block can be handed out again while the other stream still has work queued on it (a caller that drops its
+                    # reference early - or a deferred join - would otherwise race with the block's next owner)
+                    _record_stream(x, st)
+                    out[i] = model.predict(x)
+                    _record_stream(out[i], main)
             done = torch.cuda.Event()
             done.record(st)
             joins.append(done)
@@ -334,10 +378,7 @@ def measure_costs(members, raws: Sequence[bytes], dist=None, rank: int = 0) -> L
     costs = torch.zeros((len(members),), dtype=torch.float64, device="cuda")
     if rank == 0:
         batch = pipeline.decode_jpegs(list(raws))
-        inputs = {}
-        for spec, _ in members:
-            if spec.input_hw not in inputs:
-                inputs[spec.input_hw] = batch.resized(spec.input_hw, spec.input_hw)
+        inputs = member_inputs(batch, members)
         ms = MemberStreams(2)
         ms._calibrate(members, inputs)          # warm-up: first-launch costs (module load, attribute calls)
         ms._calibrate(members, inputs)
@@ -370,11 +411,8 @@ def _score_batch(staged, members, flags: Optional[np.ndarray] = None, after_fork
     global _MEMBER_STREAMS
     if _MEMBER_STREAMS is None:
         _MEMBER_STREAMS = MemberStreams(default_streams())
-    cache: Dict[int, torch.Tensor] = {}
-    for spec, _ in members:
-        hw = spec.input_hw
-        if hw not in cache:
-            cache[hw] = batch.resized(hw, hw)
+    cache = member_inputs(batch, members)
+
     def one_pass(inputs):
         from . import ops
         preds = _MEMBER_STREAMS.predict_all(members, inputs, after_fork=hook[0])     # [n, C] fp32 each
@@ -388,7 +426,7 @@ def _score_batch(staged, members, flags: Optional[np.ndarray] = None, after_fork
         return one_pass(cache)
     acc = None
     for fl in flags:                                             # augment AFTER decode+resize, as dataset.py:88-99 maps it
-        aug = {hw: pipeline.apply_augment(x, fl[:, 0], fl[:, 1], fl[:, 2]) for hw, x in cache.items()}
+        aug = {key: pipeline.apply_augment(x, fl[:, 0], fl[:, 1], fl[:, 2]) for key, x in cache.items()}
         s = one_pass(aug)
         acc = s if acc is None else acc + s
     return acc / float(len(flags))

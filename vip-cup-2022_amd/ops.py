@@ -45,6 +45,55 @@ def _chk16(t: torch.Tensor, name: str):
                             f"contiguous={t.is_contiguous()}")
 
 
+def _chk32(t: torch.Tensor, name: str):
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise _abi.VipError(f"{name}: expected a contiguous CUDA float32 tensor (strict path), got {t.dtype} {t.device} "
+                            f"contiguous={t.is_contiguous()}")
+
+
+def _is32(t: torch.Tensor, name: str) -> bool:
+    """True: ``t`` is an fp32 activation (STRICT path, the ``_s32`` entry points); False: fp16 (fast path).  Raises otherwise."""
+    if t.dtype == torch.float32:
+        _chk32(t, name)
+        return True
+    _chk16(t, name)
+    return False
+
+
+# ---- precision mode ------------------------------------------------------------------------------------------------------------
+# "fast":   fp16 storage of activations and weights, fp32 accumulate (the throughput path; member logits at the fp16 storage floor).
+# "strict": fp32 storage, fp32 matrix arithmetic (v_mfma_f32_32x32x2_f32), libm activations - what the reference computes in
+#           (main.py:107-109, TensorFlow fp32) and the mode in which BASELINE.json's |dz| <= 1e-3 holds for every member.
+# The mode is a property of the WEIGHTS a model was constructed with (``precision("strict")`` around the constructor) and of the
+# activation dtype it is fed: every operator below dispatches on ``x.dtype``.
+PRECISION = os.environ.get("VIP_PRECISION", "fast")
+PRECISIONS = ("fast", "strict")
+
+
+class precision:
+    """Context: models constructed inside carry weights for the given precision mode (see PRECISION)."""
+
+    def __init__(self, mode: str):
+        if mode not in PRECISIONS:
+            raise ValueError(f"precision {mode!r}: expected one of {PRECISIONS}")
+        self.mode = mode
+
+    def __enter__(self):
+        global PRECISION
+        self._old, PRECISION = PRECISION, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self._old
+        return False
+
+
+def act_dtype(mode: Optional[str] = None) -> torch.dtype:
+    """storage type of activations in a precision mode"""
+    return torch.float32 if (mode or PRECISION) == "strict" else torch.float16
+
+
 @dataclass
 class ConvWeight:
     """Device-resident conv / dense weight in the kernel's layout: ``w[Cout][kh*kw*Cin_g (padded to ldw)]``
@@ -64,6 +113,11 @@ class ConvWeight:
     @property
     def cin(self):
         return self.cin_g * self.groups
+
+    @property
+    def strict(self):
+        """fp32 weights (constructed under ``precision("strict")``)"""
+        return self.w.dtype == torch.float32
 
     @property
     def ldw(self):
@@ -218,6 +272,13 @@ def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], gr
         if b is not None:
             b = torch.cat([b, b.new_zeros(pad_cout_to - cout)])
         cout = pad_cout_to
+    if PRECISION == "strict":          # fp32 weights as they are: nothing to round, nothing to calibrate
+        if cin_g % 4 or (cout // groups) % 4:
+            raise _abi.VipError(f"make_conv_weight(strict): Cin_g={cin_g} / Cout_g={cout // groups} must be multiples of 4 "
+                                "(pad_cin_to / pad_cout_to)")
+        w32 = k.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin_g).contiguous()
+        return ConvWeight(w=w32.to(device), bias=None if b is None else b.to(device).contiguous(), kh=kh, kw=kw, cin_g=cin_g,
+                          cout=cout, groups=groups, alg_cin_g=alg_cin_g)
     # round along (channel, tap): the taps of one input channel see the same mean activation, so their rounding
     # errors are diffused into each other first; the carry then runs on across channels
     hilo = hilo and hilo_eligible(kh, kw, cin_g * groups, groups)
@@ -268,7 +329,10 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
     either way.
     ``x`` may carry more channels than the weight consumes (``cin_off`` selects the slice); ``out`` may
     be a wider tensor written at ``cout_off`` (concat-free channel splits / joins)."""
-    _chk16(x, "conv2d.x")
+    if _is32(x, "conv2d.x"):
+        return _conv2d_s32(x, cw, stride, pad, act, act_post, residual, out, cin_off, cout_off, gate)
+    if cw.strict:
+        raise _abi.VipError("conv2d: fp16 activations with strict (fp32) weights - build the model and its input in the same precision")
     if gate is not None and _UNFUSED:
         assert gate.shape == (x.shape[0], 2, cw.cin) and x.shape[3] == cw.cin and cin_off == 0
         x, gate = scale_add_act(x, gate, None, None), None
@@ -324,9 +388,49 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
     return out
 
 
+def _conv2d_s32(x, cw: ConvWeight, stride, pad, act, act_post, residual, out, cin_off, cout_off, gate):
+    """STRICT conv2d: fp32 x / weights / residual / out, vip_conv2d_nhwc_s32; a gate [B, Cin] fp32 is multiplied in first."""
+    if not cw.strict:
+        raise _abi.VipError("conv2d: fp32 activations with fp16 weights - build the model under ops.precision('strict')")
+    if gate is not None:
+        assert gate.shape == (x.shape[0], cw.cin) and x.shape[3] == cw.cin and cin_off == 0, (gate.shape, x.shape, cw.cin)
+        x = scale_add_act(x, gate, None, None)
+    B, H, W, ldx = x.shape
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    pt, pb, pl, pr = pad
+    Ho = (H + pt + pb - cw.kh) // sh + 1
+    Wo = (W + pl + pr - cw.kw) // sw + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, cw.cout), dtype=torch.float32, device=x.device)
+    else:
+        _chk32(out, "conv2d.out")
+        assert out.shape[:3] == (B, Ho, Wo), (out.shape, (B, Ho, Wo))
+    if residual is not None:
+        _chk32(residual, "conv2d.residual")
+        assert residual.shape[:3] == (B, Ho, Wo) and residual.shape[3] >= cw.cout
+    d = _abi.ConvDesc(B=B, H=H, W=W, Cin=cw.cin, Cout=cw.cout, kh=cw.kh, kw=cw.kw, sh=sh, sw=sw, pt=pt, pl=pl, Ho=Ho, Wo=Wo,
+                      groups=cw.groups, ldx=ldx, cin_off=cin_off, ldy=out.shape[3], cout_off=cout_off,
+                      ldr=0 if residual is None else residual.shape[3], res_off=0, ldw=cw.ldw, act_pre=_act(act), act_post=_act(act_post))
+    tok = None
+    if _PROF is not None:
+        M = B * Ho * Wo
+        kk = cw.kh * cw.kw * cw.alg_cin_g
+        tok = _PROF.start("sconv_kernel", 2.0 * M * cw.cout * kk,
+                          4.0 * (B * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()),
+                          f"M={M} N={cw.cout} K={cw.kh * cw.kw * cw.cin_g} k{cw.kh} s{sh} g{cw.groups}")
+    st = _abi.lib().vip_conv2d_nhwc_s32(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), C.byref(d), _stream())
+    if tok is not None:
+        _PROF.stop(tok)
+    _abi.check(st, "vip_conv2d_nhwc_s32")
+    return out
+
+
 def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Optional[torch.Tensor] = None):
     """Dense over the last axis of ``x`` (any leading shape)."""
-    _chk16(x, "dense.x")
+    if _is32(x, "dense.x"):
+        lead, K = x.shape[:-1], x.shape[-1]
+        r4 = None if residual is None else residual.reshape(-1, 1, 1, cw.cout)
+        return _conv2d_s32(x.reshape(-1, 1, 1, K), cw, 1, (0, 0, 0, 0), act, act_post, r4, None, 0, 0, None).reshape(*lead, cw.cout)
     if _CALIB and cw.err is not None:
         _bias_correct(cw, x)
     if _EXACT and cw.exact is not None:
@@ -361,7 +465,10 @@ def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual:
     """``fc2(act(fc1(LN(x)))) (+ residual)`` over the last axis; ``ln = (gamma, beta, eps)`` or None.  One fused launch
     (LayerNorm in the prologue, hidden tensor in registers) when the C ABI supports the shape, otherwise LayerNorm +
     two Dense launches - same arithmetic either way."""
-    _chk16(x, "mlp.x")
+    if _is32(x, "mlp.x"):        # STRICT: LayerNorm, Dense + activation, Dense (+ residual) as three fp32 launches
+        if ln is not None:
+            x = layernorm(x, ln[0], ln[1], float(ln[2]))
+        return dense(dense(x, fc1, act=act), fc2, residual=residual)
     C_ = x.shape[-1]
     M = x.numel() // C_
     hid = fc1.cout
@@ -396,7 +503,8 @@ def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmo
     One launch (vip_se_gate_f16: a workgroup per image, matrix-vector products out of L2) when the two weight matrices
     are small - every image re-reads them, so for wide gates (ResNet-RS / ResNeSt: Cr = C/4) the pool + two batched
     GEMMs are cheaper and are used instead (the last one with the split epilogue)."""
-    _chk16(x, "se_gate.x")
+    if _is32(x, "se_gate.x"):    # STRICT: pool -> Dense -> Dense, the gate is a plain fp32 [B, C]
+        return dense(dense(global_avgpool(x), fc1, act=act1), fc2, act=act2)
     B, H, W, Cc = x.shape
     assert fc1.groups == 1 and fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1
     assert fc1.cin == Cc and fc2.cin == fc1.cout, (fc1.cin, Cc, fc2.cin, fc1.cout)
@@ -414,7 +522,8 @@ def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmo
 def dense_split(x: torch.Tensor, cw: ConvWeight, act=None) -> torch.Tensor:
     """Dense on a few rows with the output as two fp16 planes ``[M, 2, N]`` (``fp16(v)``, ``fp16(v - fp16(v))``).  ``x`` is ``[M, K]``
     or itself split, ``[M, 2, K]`` (a pooled vector from ``global_avgpool(split=True)`` or the previous layer of the chain)."""
-    _chk16(x, "dense_split.x")
+    if _is32(x, "dense_split.x"):    # STRICT: fp32 vectors need no hi / lo planes
+        return dense(x, cw, act=act)
     split_in = x.dim() == 3
     assert x.dim() == 2 or (split_in and x.shape[1] == 2), x.shape
     if _CALIB and cw.err is not None:
@@ -437,14 +546,19 @@ def dense_split(x: torch.Tensor, cw: ConvWeight, act=None) -> torch.Tensor:
 
 def dwconv2d(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride=1, pad=(0, 0, 0, 0), act=None):
     """Depthwise conv; ``w_khwc`` fp32 ``[k,k,C]``, bias fp32 ``[C]``."""
-    _chk16(x, "dwconv2d.x")
+    s32 = _is32(x, "dwconv2d.x")
     if w_khwc.dtype != torch.float32 or not w_khwc.is_contiguous() or w_khwc.shape != (k, k, x.shape[-1]):
         raise ValueError("dwconv2d: the filter must be a contiguous fp32 [k,k,C] tensor")
     B, H, W, Cc = x.shape
     pt, pb, pl, pr = pad
     Ho = (H + pt + pb - k) // stride + 1
     Wo = (W + pl + pr - k) // stride + 1
-    out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float16, device=x.device)
+    out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    if s32:
+        st = _abi.lib().vip_dwconv2d_nhwc_s32(_p(x), _p(w_khwc), _p(bias), _p(out), B, H, W, Cc, k, stride, pt, pl, Ho, Wo,
+                                              _act(act), _stream())
+        _abi.check(st, "vip_dwconv2d_nhwc_s32")
+        return out
     st = _abi.lib().vip_dwconv2d_nhwc_f16(_p(x), _p(w_khwc), _p(bias), _p(out), B, H, W, Cc, k, stride, pt, pl,
                                           Ho, Wo, _act(act), _stream())
     _abi.check(st, "vip_dwconv2d_nhwc_f16")
@@ -459,7 +573,7 @@ def mbconv_expand_dw(x, cw: ConvWeight, w_khwc: torch.Tensor, dw_bias: Optional[
     the two HBM-bound kernels hide their swish evaluations (exp + rcp each) behind memory, the fused one is VALU-bound on them plus
     the halo recompute.  Calibration / exact-weight passes always run the two launches."""
     B, H, W, ldx = x.shape
-    ok = (not _UNFUSED and os.environ.get("VIP_MBCONV_FUSED", "0") == "1" and cw.kh == cw.kw == 1 and cw.groups == 1 and ldx == cw.cin
+    ok = (not _UNFUSED and x.dtype == torch.float16 and os.environ.get("VIP_MBCONV_FUSED", "0") == "1" and cw.kh == cw.kw == 1 and cw.groups == 1 and ldx == cw.cin
           and w_khwc.shape == (k, k, cw.cout) and _abi.lib().vip_mbconv_expand_dw_supported(cw.cin, cw.cout, k, stride))
     if not ok:
         return dwconv2d(conv2d(x, cw, act=act), w_khwc, dw_bias, k, stride, pad, act=act)
@@ -481,10 +595,14 @@ def mbconv_expand_dw(x, cw: ConvWeight, w_khwc: torch.Tensor, dw_bias: Optional[
 
 
 def layernorm(x, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
-    _chk16(x, "layernorm.x")
+    s32 = _is32(x, "layernorm.x")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     out = torch.empty_like(x)
+    if s32:
+        st = _abi.lib().vip_layernorm_s32(_p(x), _p(gamma), _p(beta), _p(out), rows, Cc, float(eps), _stream())
+        _abi.check(st, "vip_layernorm_s32")
+        return out
     st = _abi.lib().vip_layernorm_f16(_p(x), _p(gamma), _p(beta), _p(out), rows, Cc, float(eps), _stream())
     _abi.check(st, "vip_layernorm_f16")
     return out
@@ -496,7 +614,7 @@ POOL_MAX_ZEROPAD, POOL_AVG_VALID, POOL_AVG_FULL = 0, 1, 2
 def pool2d(x, k: int, stride: int, pad=(0, 0, 0, 0), mode=POOL_MAX_ZEROPAD, out_hw=None):
     """``out_hw`` = (Ho, Wo) asks for fewer output rows / columns than the padding implies (a top-left crop); with k = 1,
     stride 1 and zero-pad max pooling the op is a zero-padded copy (GCViT FitWindow) or a crop (level.py:61)."""
-    _chk16(x, "pool2d.x")
+    s32 = _is32(x, "pool2d.x")
     B, H, W, Cc = x.shape
     pt, pb, pl, pr = pad
     Ho = (H + pt + pb - k) // stride + 1
@@ -504,7 +622,11 @@ def pool2d(x, k: int, stride: int, pad=(0, 0, 0, 0), mode=POOL_MAX_ZEROPAD, out_
     if out_hw is not None:
         assert out_hw[0] <= Ho and out_hw[1] <= Wo
         Ho, Wo = out_hw
-    out = torch.empty((B, Ho, Wo, Cc), dtype=torch.float16, device=x.device)
+    out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    if s32:
+        st = _abi.lib().vip_pool2d_nhwc_s32(_p(x), _p(out), B, H, W, Cc, Cc, Cc, k, stride, pt, pl, Ho, Wo, mode, _stream())
+        _abi.check(st, "vip_pool2d_nhwc_s32")
+        return out
     st = _abi.lib().vip_pool2d_nhwc_f16(_p(x), _p(out), B, H, W, Cc, Cc, Cc, k, stride, pt, pl, Ho, Wo, mode,
                                         _stream())
     _abi.check(st, "vip_pool2d_nhwc_f16")
@@ -513,9 +635,13 @@ def pool2d(x, k: int, stride: int, pad=(0, 0, 0, 0), mode=POOL_MAX_ZEROPAD, out_
 
 def global_avgpool(x, split: bool = False):
     """[B,H,W,C] (or [B,N,C]) -> [B,C]; ``split``: [B,2,C], the mean as a hi and a lo fp16 plane (for ``dense_split``)."""
-    _chk16(x, "global_avgpool.x")
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
+    if _is32(x, "global_avgpool.x"):     # STRICT: fp32 [B, C] whatever ``split`` says
+        out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        st = _abi.lib().vip_global_avgpool_s32(_p(x), _p(out), B, HW, Cc, Cc, _stream())
+        _abi.check(st, "vip_global_avgpool_s32")
+        return out
     out = torch.empty((B, 2, Cc) if split else (B, Cc), dtype=torch.float16, device=x.device)
     fn = "vip_global_avgpool_split_f16" if split else "vip_global_avgpool_f16"
     st = getattr(_abi.lib(), fn)(_p(x), _p(out), B, HW, Cc, Cc, _stream())
@@ -526,12 +652,16 @@ def global_avgpool(x, split: bool = False):
 def gap_dense_f32(x, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     """Classifier head: mean over the middle axes of ``x`` ([B,...,C]) then Dense -> fp32 ``[B,N]``.
     ``w_nc`` fp32 ``[N,C]``."""
-    _chk16(x, "gap_dense_f32.x")
+    s32 = _is32(x, "gap_dense_f32.x")
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
     N = w_nc.shape[0]
     assert w_nc.dtype == torch.float32 and w_nc.shape == (N, Cc) and w_nc.is_contiguous()
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    if s32:
+        st = _abi.lib().vip_gap_ln_dense_s32(_p(x), None, None, 0.0, _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, HW * Cc, N, _stream())
+        _abi.check(st, "vip_gap_ln_dense_s32")
+        return out
     st = _abi.lib().vip_gap_dense_f32(_p(x), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, N, _stream())
     _abi.check(st, "vip_gap_dense_f32")
     return out
@@ -540,13 +670,18 @@ def gap_dense_f32(x, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
 def gap_ln_dense_f32(x, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     """Classifier head with a LayerNorm on the pooled vector: mean over the middle axes of ``x`` ([B,...,C]) -> LayerNorm over C
     -> Dense, fp32 throughout -> fp32 ``[B,N]``.  ``gamma``/``beta`` fp32 ``[C]``, ``w_nc`` fp32 ``[N,C]``."""
-    _chk16(x, "gap_ln_dense_f32.x")
+    s32 = _is32(x, "gap_ln_dense_f32.x")
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
     N = w_nc.shape[0]
     assert w_nc.dtype == torch.float32 and w_nc.shape == (N, Cc) and w_nc.is_contiguous()
     assert gamma.dtype == beta.dtype == torch.float32 and gamma.shape == beta.shape == (Cc,)
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    if s32:
+        st = _abi.lib().vip_gap_ln_dense_s32(_p(x), _p(gamma), _p(beta), float(eps), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc,
+                                             HW * Cc, N, _stream())
+        _abi.check(st, "vip_gap_ln_dense_s32")
+        return out
     st = _abi.lib().vip_gap_ln_dense_f32(_p(x), _p(gamma), _p(beta), float(eps), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, N,
                                          _stream())
     _abi.check(st, "vip_gap_ln_dense_f32")
@@ -587,9 +722,20 @@ def ensemble_mean(scores: torch.Tensor) -> torch.Tensor:
 def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
     """act(x * scale[b,c] + residual); with ``act2`` returns ``(y, act2(y))`` from one launch.
     ``scale`` is [B, C] fp16 or a split gate [B, 2, C] (planes summed in fp32)."""
-    _chk16(x, "scale_add_act.x")
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
+    if _is32(x, "scale_add_act.x"):      # STRICT: scale is a plain fp32 [B, C]
+        if scale is not None:
+            _chk32(scale, "scale_add_act.scale")
+            assert scale.shape == (B, Cc), scale.shape
+        if residual is not None:
+            _chk32(residual, "scale_add_act.residual")
+            assert residual.shape == x.shape
+        out = torch.empty_like(x)
+        out2 = torch.empty_like(x) if act2 is not None else None
+        st = _abi.lib().vip_scale_add_act_s32(_p(x), _p(scale), _p(residual), _p(out), _p(out2), B, HW, Cc, _act(act), _act(act2), _stream())
+        _abi.check(st, "vip_scale_add_act_s32")
+        return out if act2 is None else (out, out2)
     planes = 1
     if scale is not None:
         _chk16(scale, "scale_add_act.scale")
@@ -608,15 +754,20 @@ def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
 
 def window_attention(qkv, q_global, bias_table, heads: int, ws: int, scale: float):
     """GCViT window attention core on feature-map layout.  qkv ``[B,Hp,Wp,nq*C]``; q_global ``[B,ws*ws,C]`` or None."""
-    _chk16(qkv, "window_attention.qkv")
+    s32 = _is32(qkv, "window_attention.qkv")
     B, Hp, Wp, CC = qkv.shape
     nq = 2 if q_global is not None else 3
     Cc = CC // nq
     if q_global is not None:
-        _chk16(q_global, "window_attention.q_global")
+        (_chk32 if s32 else _chk16)(q_global, "window_attention.q_global")
         assert q_global.numel() == B * ws * ws * Cc
     assert bias_table.dtype == torch.float32 and bias_table.shape == ((2 * ws - 1) ** 2, heads)
-    out = torch.empty((B, Hp, Wp, Cc), dtype=torch.float16, device=qkv.device)
+    out = torch.empty((B, Hp, Wp, Cc), dtype=qkv.dtype, device=qkv.device)
+    if s32:
+        st = _abi.lib().vip_window_attn_fwd_s32(_p(qkv), _p(q_global), _p(bias_table), _p(out), B, Hp, Wp, Cc, heads, ws, nq,
+                                                float(scale), _stream())
+        _abi.check(st, "vip_window_attn_fwd_s32")
+        return out
     tok = None
     if _PROF is not None:
         # algorithmic work of the attention core (SURVEY.md §8d): 4*N^2*hd FLOPs and 4*N*hd fp16 elements
@@ -634,30 +785,40 @@ def window_attention(qkv, q_global, bias_table, heads: int, ws: int, scale: floa
 
 def mhsa(qkv, heads: int, scale: float):
     """ViT attention core: qkv ``[B,N,3D]`` -> ``[B,N,D]``."""
-    _chk16(qkv, "mhsa.qkv")
+    s32 = _is32(qkv, "mhsa.qkv")
     B, N, D3 = qkv.shape
     D = D3 // 3
-    out = torch.empty((B, N, D), dtype=torch.float16, device=qkv.device)
+    out = torch.empty((B, N, D), dtype=qkv.dtype, device=qkv.device)
+    if s32:
+        st = _abi.lib().vip_mhsa_fwd_s32(_p(qkv), _p(out), B, N, D, heads, float(scale), _stream())
+        _abi.check(st, "vip_mhsa_fwd_s32")
+        return out
     st = _abi.lib().vip_mhsa_fwd_f16(_p(qkv), _p(out), B, N, D, heads, float(scale), _stream())
     _abi.check(st, "vip_mhsa_fwd_f16")
     return out
 
 
-def to_device_nhwc8(x_nhwc3: torch.Tensor, device="cuda") -> torch.Tensor:
-    """Plumbing for callers that already hold decoded float images: [B,H,W,3] float -> fp16 NHWC with the
-    channel axis zero-padded to 8 (the layout vip_resize_bicubic_norm_f16 emits)."""
+def to_device_nhwc8(x_nhwc3: torch.Tensor, device="cuda", dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Plumbing for callers that already hold decoded float images: [B,H,W,3] float -> NHWC with the channel axis zero-padded
+    to 8 (the layout vip_resize_bicubic_norm_f16 / _s32 emit), fp16 or - ``dtype=torch.float32``, the STRICT path - fp32."""
     B, H, W, Cc = x_nhwc3.shape
-    out = torch.zeros((B, H, W, 8), dtype=torch.float16, device=device)
-    out[..., :Cc] = x_nhwc3.to(device=device, dtype=torch.float16)
+    dtype = dtype or torch.float16
+    out = torch.zeros((B, H, W, 8), dtype=dtype, device=device)
+    out[..., :Cc] = x_nhwc3.to(device=device, dtype=dtype)
     return out
 
 
 def vit_tokens(patches, cls_token, pos_embed):
     """[B,NP,D] patches + cls [D] + pos [NP+1,D] -> [B,NP+1,D] (tfimm vit.py:419-426)."""
-    _chk16(patches, "vit_tokens.patches")
+    s32 = _is32(patches, "vit_tokens.patches")
     B, NP, D = patches.shape
     assert cls_token.numel() == D and pos_embed.numel() == (NP + 1) * D
-    out = torch.empty((B, NP + 1, D), dtype=torch.float16, device=patches.device)
+    assert cls_token.dtype == pos_embed.dtype == patches.dtype, "vit_tokens: cls / pos must be stored in the activation dtype"
+    out = torch.empty((B, NP + 1, D), dtype=patches.dtype, device=patches.device)
+    if s32:
+        st = _abi.lib().vip_vit_tokens_s32(_p(patches), _p(cls_token), _p(pos_embed), _p(out), B, NP, D, _stream())
+        _abi.check(st, "vip_vit_tokens_s32")
+        return out
     st = _abi.lib().vip_vit_tokens_f16(_p(patches), _p(cls_token), _p(pos_embed), _p(out), B, NP, D, _stream())
     _abi.check(st, "vip_vit_tokens_f16")
     return out
@@ -665,11 +826,15 @@ def vit_tokens(patches, cls_token, pos_embed):
 
 def cls_dense_f32(tokens, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     """Dense head on token 0 of ``[B,N,D]`` (ViT ``head(norm(x)[:, 0])``) -> fp32 ``[B,classes]``."""
-    _chk16(tokens, "cls_dense_f32.tokens")
+    s32 = _is32(tokens, "cls_dense_f32.tokens")
     B, N, D = tokens.shape
     n_out = w_nc.shape[0]
     assert w_nc.dtype == torch.float32 and w_nc.shape == (n_out, D) and w_nc.is_contiguous()
     out = torch.empty((B, n_out), dtype=torch.float32, device=tokens.device)
+    if s32:
+        st = _abi.lib().vip_gap_ln_dense_s32(_p(tokens), None, None, 0.0, _p(w_nc), _p(bias), _p(out), B, 1, D, D, N * D, n_out, _stream())
+        _abi.check(st, "vip_gap_ln_dense_s32")
+        return out
     st = _abi.lib().vip_gap_dense_f32(_p(tokens), _p(w_nc), _p(bias), _p(out), B, 1, D, N * D, n_out, _stream())
     _abi.check(st, "vip_gap_dense_f32")
     return out
@@ -678,11 +843,15 @@ def cls_dense_f32(tokens, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
 def mul(a: torch.Tensor, b: torch.Tensor, c: int, a_off: int = 0, b_off: int = 0) -> torch.Tensor:
     """``a[..., a_off:a_off+c] * b[..., b_off:b_off+c]`` -> contiguous ``[..., c]`` (the operands are read in place as
     channel slices of their full tensors)."""
-    _chk16(a, "mul.a")
-    _chk16(b, "mul.b")
+    s32 = _is32(a, "mul.a")
+    (_chk32 if s32 else _chk16)(b, "mul.b")
     assert a.shape[:-1] == b.shape[:-1]
     rows = a.numel() // a.shape[-1]
-    out = torch.empty((*a.shape[:-1], c), dtype=torch.float16, device=a.device)
+    out = torch.empty((*a.shape[:-1], c), dtype=a.dtype, device=a.device)
+    if s32:
+        st = _abi.lib().vip_mul_s32(_p(a), _p(b), _p(out), rows, c, a.shape[-1], a_off, b.shape[-1], b_off, c, 0, _stream())
+        _abi.check(st, "vip_mul_s32")
+        return out
     st = _abi.lib().vip_mul_f16(_p(a), _p(b), _p(out), rows, c, a.shape[-1], a_off, b.shape[-1], b_off, c, 0, _stream())
     _abi.check(st, "vip_mul_f16")
     return out
@@ -691,10 +860,16 @@ def mul(a: torch.Tensor, b: torch.Tensor, c: int, a_off: int = 0, b_off: int = 0
 def radix_combine(x, scale, radix: int = 2):
     """ResNeSt split-attention combine: x ``[B,H,W,radix*C]``, scale ``[B,radix*C]`` or split ``[B,2,radix*C]``
     -> ``[B,H,W,C]``."""
-    _chk16(x, "radix_combine.x")
-    _chk16(scale, "radix_combine.scale")
     B, H, W, RC = x.shape
     Cc = RC // radix
+    if _is32(x, "radix_combine.x"):
+        _chk32(scale, "radix_combine.scale")
+        assert scale.shape == (B, RC), scale.shape
+        out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=x.device)
+        st = _abi.lib().vip_radix_combine_s32(_p(x), _p(scale), _p(out), B, H * W, Cc, radix, _stream())
+        _abi.check(st, "vip_radix_combine_s32")
+        return out
+    _chk16(scale, "radix_combine.scale")
     assert scale.shape in ((B, RC), (B, 2, RC)), scale.shape
     out = torch.empty((B, H, W, Cc), dtype=torch.float16, device=x.device)
     st = _abi.lib().vip_radix_combine2_f16(_p(x), _p(scale), scale.dim() - 1, _p(out), B, H * W, Cc, radix, _stream())

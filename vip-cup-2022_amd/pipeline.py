@@ -70,13 +70,15 @@ class DecodedBatch:
     def __len__(self):
         return self.rgb.shape[0]
 
-    def resized(self, out_h: int, out_w: int, c_out: int = 8) -> torch.Tensor:
-        """cast -> tf.image.resize(bicubic) -> /255 (dataset/dataset.py:31-38) -> fp16 NHWC, channels padded."""
+    def resized(self, out_h: int, out_w: int, c_out: int = 8, dtype: torch.dtype = torch.float16) -> torch.Tensor:
+        """cast -> tf.image.resize(bicubic) -> /255 (dataset/dataset.py:31-38) -> NHWC, channels padded; fp16, or with
+        ``dtype=torch.float32`` (the STRICT path) the unrounded fp32 values the reference's pipeline produces."""
         n, maxH, maxW, _ = self.rgb.shape
-        out = torch.empty((n, out_h, out_w, c_out), dtype=torch.float16, device=self.rgb.device)
-        st = _abi.lib().vip_resize_bicubic_norm_f16(_p(self.rgb), _p(self.sizes), _p(bicubic_table(self.rgb.device)), n,
-                                                    maxH, maxW, _p(out), out_h, out_w, c_out, _stream())
-        _abi.check(st, "vip_resize_bicubic_norm_f16")
+        out = torch.empty((n, out_h, out_w, c_out), dtype=dtype, device=self.rgb.device)
+        fn = {torch.float16: "vip_resize_bicubic_norm_f16", torch.float32: "vip_resize_bicubic_norm_s32"}[dtype]
+        st = getattr(_abi.lib(), fn)(_p(self.rgb), _p(self.sizes), _p(bicubic_table(self.rgb.device)), n,
+                                     maxH, maxW, _p(out), out_h, out_w, c_out, _stream())
+        _abi.check(st, fn)
         return out
 
 
@@ -117,8 +119,9 @@ def apply_augment(x: torch.Tensor, hflip, vflip, gray) -> torch.Tensor:
              (torch.as_tensor(gray, dtype=torch.int32) << 2)).to(x.device)
     assert flags.numel() == B
     out = torch.empty_like(x)
-    st = _abi.lib().vip_tta_augment_f16(_p(x), _p(out), _p(flags), B, H, W, Cc, _stream())
-    _abi.check(st, "vip_tta_augment_f16")
+    fn = "vip_tta_augment_s32" if x.dtype == torch.float32 else "vip_tta_augment_f16"
+    st = getattr(_abi.lib(), fn)(_p(x), _p(out), _p(flags), B, H, W, Cc, _stream())
+    _abi.check(st, fn)
     return out
 
 
@@ -130,7 +133,8 @@ class Dataset:
     ``[bs, H, W, 8]`` resident on the GPU (channels 3..7 zero), or ``(batch, labels)`` when labels were given."""
 
     def __init__(self, paths, labels, batch_size, cache, decode_fn, augment_fn, img_size, augment, repeat, shuffle,
-                 drop_remainder, seed, num_classes, device, threads):
+                 drop_remainder, seed, num_classes, device, threads, dtype=torch.float16):
+        self.dtype = dtype
         self.paths = [os.fspath(p) for p in paths]
         self.labels = None if labels is None else np.asarray(labels)
         self.batch_size, self.cache, self.decode_fn, self.augment_fn = int(batch_size), bool(cache), decode_fn, augment_fn
@@ -138,6 +142,7 @@ class Dataset:
         self.augment, self.repeat, self.shuffle, self.drop_remainder = bool(augment), bool(repeat), int(shuffle or 0), bool(drop_remainder)
         self.seed, self.num_classes, self.device, self.threads = int(seed), int(num_classes), device, threads
         self._cached: Dict[int, torch.Tensor] = {}      # image index -> [H, W, 8] fp16 (``cache=True``: decoded once, kept in HBM)
+        self._flags: Dict[int, np.ndarray] = {}         # pass -> bool [n, 3] apply_augment draws
 
     def __len__(self):
         """batches in one pass (tf.data cardinality of the un-repeated dataset)"""
@@ -188,9 +193,9 @@ class Dataset:
         fresh: Dict[int, torch.Tensor] = {}
         if todo:
             if self.decode_fn is not None:
-                x = ops.to_device_nhwc8(torch.from_numpy(np.stack(host)), self.device)
+                x = ops.to_device_nhwc8(torch.from_numpy(np.stack(host)), self.device, self.dtype)
             else:
-                x = decode_entropy(host, self.device).resized(self.img_size[0], self.img_size[1])
+                x = decode_entropy(host, self.device).resized(self.img_size[0], self.img_size[1], dtype=self.dtype)
             fresh = {i: x[j] for j, i in enumerate(todo)}
             if self.cache:
                 self._cached.update(fresh)
@@ -200,10 +205,13 @@ class Dataset:
             if self.augment_fn is not None:
                 batch = self.augment_fn(batch)
             else:       # apply_augment (dataset/augment.py:153-182): seeded draws per (pass, image) - TF's RNG stream is not reproducible
-                from .ensemble import tta_flags
-                passes = max(t for _, t in items) + 1
-                fl = tta_flags(len(self.paths), passes, self.seed)
-                sel = np.stack([fl[t, i] for i, t in items])
+                from .ensemble import tta_flags_pass
+                for t in {t for _, t in items}:             # the draws of a pass are a function of (seed, pass): built once per pass
+                    if t not in self._flags:
+                        if len(self._flags) > 4:             # a repeating dataset walks the passes in order: keep only recent ones
+                            self._flags.pop(min(self._flags))
+                        self._flags[t] = tta_flags_pass(len(self.paths), t, self.seed)
+                sel = np.stack([self._flags[t][i] for i, t in items])
                 batch = apply_augment(batch, sel[:, 0], sel[:, 1], sel[:, 2])
         if self.labels is None:
             return batch
@@ -243,17 +251,21 @@ def build_dataset(paths, labels=None, batch_size=32, cache=True, decode_fn=None,
     fallback when no CFG is passed), ``CFG.seed`` seeds the shuffle, ``CFG.num_classes`` the label encoding; ``CFG.is_train``
     is set as a side effect (:73).  ``cache`` keeps the decoded, resized batch elements resident in HBM (tf.data's in-memory
     cache); ``cache_dir`` is created when given (:70-71) but nothing is written to it."""
+    from . import ops
     if cache_dir != "" and cache is True:
         os.makedirs(cache_dir, exist_ok=True)
     img_size = tuple(dim)
     seed, num_classes = 42, 1
+    mode = None
     if CFG is not None:
         CFG.is_train = labels is not None
         img_size = tuple(getattr(CFG, "img_size", dim))
         seed = int(getattr(CFG, "seed", 42))
         num_classes = int(getattr(CFG, "num_classes", 1))
+        mode = getattr(CFG, "precision", None)
+    # batches are stored in the precision mode's activation dtype: fp16 ("fast"), fp32 ("strict": CFG.precision or ops.PRECISION)
     return Dataset(paths, labels, batch_size, cache, decode_fn, augment_fn, img_size, augment, repeat, shuffle,
-                   drop_remainder, seed, num_classes, device, threads)
+                   drop_remainder, seed, num_classes, device, threads, ops.act_dtype(mode))
 
 
 def predict_dataset(predict_batch, dataset, steps=None, verbose=0) -> np.ndarray:
@@ -261,12 +273,13 @@ def predict_dataset(predict_batch, dataset, steps=None, verbose=0) -> np.ndarray
     iterable (Keras' data handler keeps stepping while ``step < steps``, so the reference's fractional
     ``steps = max(tta * n / batch, 1)`` means its ceiling; ``None`` = until the dataset ends) and return the concatenated
     predictions as a numpy array ``[sum of batch sizes, C]`` - the caller slices off what the repeat padded (main.py:110)."""
+    import itertools
     import math
     limit = None if steps is None else int(math.ceil(float(steps)))
     outs = []
-    for k, batch in enumerate(dataset):
-        if limit is not None and k >= limit:
-            break
+    # islice stops BEFORE asking the dataset for batch number `limit` (a plain `break` after enumerate would already have pulled it:
+    # one more read + Huffman decode + H2D + IDCT + resize per predict call)
+    for k, batch in enumerate(dataset if limit is None else itertools.islice(dataset, limit)):
         x = batch[0] if isinstance(batch, (tuple, list)) else batch
         outs.append(predict_batch(x))
         if verbose:
@@ -283,10 +296,17 @@ def keras_predict(cls):
     ``tf.keras.Model.predict`` takes in main.py:109 - a dataset iterable plus ``steps`` / ``verbose`` (-> numpy ``[n, C]``)."""
     batch_predict = cls.predict
 
+    def checked(self, t):
+        prec = getattr(self, "precision", None)           # set by zoo.construct; absent on hand-built models (no check)
+        if prec is not None and t.dtype != (torch.float32 if prec == "strict" else torch.float16):
+            raise _abi.VipError(f"{type(self).__name__}.predict: a {prec} model got a {t.dtype} batch "
+                                "(DecodedBatch.resized(..., dtype=...) / build_dataset with CFG.precision pick the input dtype)")
+        return batch_predict(self, t)
+
     def predict(self, x, steps=None, verbose=0, **_keras_kwargs):
         if isinstance(x, torch.Tensor):
-            return batch_predict(self, x)
-        return predict_dataset(lambda t: batch_predict(self, t), x, steps, verbose)
+            return checked(self, x)
+        return predict_dataset(lambda t: checked(self, t), x, steps, verbose)
     predict.__doc__ = batch_predict.__doc__
     cls.predict = predict
     return cls

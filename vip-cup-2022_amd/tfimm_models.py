@@ -86,8 +86,8 @@ class ViT:
         D = cfg.embed_dim
         assert D // cfg.nb_heads == 64, "vip_mhsa_fwd_f16 implements head_dim 64"
         self.patch = ops.make_conv_weight(p["patch_embed/proj/kernel"], p["patch_embed/proj/bias"], device=dev, pad_cin_to=8)
-        self.cls = p["cls_token"].reshape(D).to(dev, torch.float16).contiguous()
-        self.pos = p["pos_embed"].reshape(-1, D).to(dev, torch.float16).contiguous()
+        self.cls = p["cls_token"].reshape(D).to(dev, ops.act_dtype()).contiguous()      # stored like an activation (fp32 when strict)
+        self.pos = p["pos_embed"].reshape(-1, D).to(dev, ops.act_dtype()).contiguous()
         self.blocks = []
         for j in range(cfg.nb_blocks):
             b = f"blocks/{j}"

@@ -153,11 +153,7 @@ class Workload:
             midx = self.plan.units[self.rank][s]
             sub = [self.models[m] for m in midx]
             batch = self._next_batch()
-            cache = {}
-            for spec, _ in sub:
-                hw = spec.input_hw
-                if hw not in cache:
-                    cache[hw] = batch.resized(hw, hw)        # cast + bicubic + /255 (dataset.py:31-38)
+            cache = ensemble.member_inputs(batch, sub)       # cast + bicubic + /255 (dataset.py:31-38), once per (resolution, dtype)
             preds, joins = streams.predict_all(sub, cache, after_fork=self._decode_next if self._prefetch else None, defer_join=True)
             units.append((s, midx, preds, joins, cache))     # the inputs stay referenced until the unit is joined
         if not pipelined:

@@ -125,23 +125,40 @@ def build_params(name: str, calibrated: bool = True):
     return params
 
 
-def construct(spec: MemberSpec, params, bias_calibration: bool = True):
-    """``spec.ctor(params)`` followed, on a GPU, by one calibration pass (ops.calibration: the image-independent part of
-    the fp16 weight-rounding error is folded into the fp32 biases).  ``bias_calibration=False`` gives the plain fp16
-    model."""
+def construct(spec: MemberSpec, params, bias_calibration: bool = True, precision: str = None, calibration_batch=None):
+    """``spec.ctor(params)`` in a precision mode (``ops.PRECISION`` when None; env ``VIP_PRECISION``):
+
+    * ``"fast"``: fp16 weights, followed on a GPU by one calibration pass (ops.calibration: the image-independent part of the fp16
+      weight-rounding error is folded into the fp32 biases) over ``calibration_batch`` (a ``pipeline.DecodedBatch``; default: the
+      seeded synthetic batch ``pipeline.calibration_batch()`` - pass a few REAL images when the checkpoints are real, the correction
+      needs typical per-channel input means).  ``bias_calibration=False`` (or env ``VIP_BIAS_CALIBRATION=0``) gives the plain fp16 model.
+    * ``"strict"``: fp32 weights exactly as in the checkpoint, nothing to calibrate; the model takes fp32 inputs.
+
+    The mode is recorded as ``model.precision``; ``ensemble.member_input`` feeds each member the input dtype it was built for."""
     from . import ops, pipeline
-    if os.environ.get("VIP_BIAS_CALIBRATION", "1") == "0":     # profiling runs: keep the calibration launches out of the trace
-        bias_calibration = False
-    if not (bias_calibration and torch.cuda.is_available()):
-        return spec.ctor(params)
-    ops.KEEP_ROUNDING_ERROR = True
-    try:
-        model = spec.ctor(params)
-    finally:
-        ops.KEEP_ROUNDING_ERROR = False
-    calibrate(model, pipeline.calibration_batch().resized(spec.input_hw, spec.input_hw))
-    torch.cuda.synchronize()
-    return model
+    mode = precision or ops.PRECISION
+    if mode == "strict":
+        with ops.precision("strict"):
+            model = spec.ctor(params)
+        model.precision = "strict"
+        return model
+    with ops.precision("fast"):
+        if os.environ.get("VIP_BIAS_CALIBRATION", "1") == "0":     # profiling runs: keep the calibration launches out of the trace
+            bias_calibration = False
+        if not (bias_calibration and torch.cuda.is_available()):
+            model = spec.ctor(params)
+            model.precision = "fast"
+            return model
+        ops.KEEP_ROUNDING_ERROR = True
+        try:
+            model = spec.ctor(params)
+        finally:
+            ops.KEEP_ROUNDING_ERROR = False
+        model.precision = "fast"
+        batch = calibration_batch if calibration_batch is not None else pipeline.calibration_batch()
+        calibrate(model, batch.resized(spec.input_hw, spec.input_hw))
+        torch.cuda.synchronize()
+        return model
 
 
 def calibrate(model, x):
@@ -169,9 +186,10 @@ def calibrate(model, x):
     return model
 
 
-def build_member(name: str, calibrated: bool = True, bias_calibration: bool = True) -> Tuple[MemberSpec, object]:
+def build_member(name: str, calibrated: bool = True, bias_calibration: bool = True, precision: str = None,
+                 calibration_batch=None) -> Tuple[MemberSpec, object]:
     spec = MEMBERS[name]
-    return spec, construct(spec, build_params(name, calibrated), bias_calibration)
+    return spec, construct(spec, build_params(name, calibrated), bias_calibration, precision, calibration_batch)
 
 
 def by_ckpt_name(ckpt_name: str):
@@ -191,6 +209,7 @@ def _fold_mean_cls():
 
         def __init__(self, folds):
             self.folds = folds
+            self.precision = getattr(folds[0], "precision", "fast")
 
         def predict(self, x):
             ps = [m.predict(x) for m in self.folds]
@@ -229,15 +248,17 @@ def match_variable_names(spec: MemberSpec, params):
     return params
 
 
-def load_model(path: str, compile: bool = False):
+def load_model(path: str, compile: bool = False, precision: str = None, bias_calibration: bool = True, calibration_batch=None):
     """Counterpart of ``tf.keras.models.load_model(path, compile=False)`` (main.py:107) for this build's checkpoint formats:
     ``path`` = ``.../ckpts/<member directory>/ckpt/<fold>.npz`` (a flat dict of Keras-named arrays) or ``<fold>.h5`` (a Keras weight /
     model file, ``read_checkpoint``).  The member graph is picked from
     the directory name exactly as the reference picks its batch size from it (main.py:70-71,85); the returned object has the
-    ``predict(dataset, steps, verbose) -> np.ndarray [n, C]`` of a Keras model."""
+    ``predict(dataset, steps, verbose) -> np.ndarray [n, C]`` of a Keras model.  ``precision`` / ``bias_calibration`` /
+    ``calibration_batch``: see ``construct``; a strict model takes fp32 batches (``pipeline.build_dataset`` yields them when
+    ``CFG.precision == "strict"`` or ``ops.PRECISION`` is)."""
     model_name = os.path.basename(os.path.dirname(os.path.dirname(os.path.abspath(path))))
     key = by_ckpt_name(model_name)
     if key is None:
         raise ValueError(f"load_model: no graph for checkpoint directory {model_name!r}")
     spec = MEMBERS[key]
-    return construct(spec, match_variable_names(spec, read_checkpoint(path)))
+    return construct(spec, match_variable_names(spec, read_checkpoint(path)), bias_calibration, precision, calibration_batch)
