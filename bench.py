@@ -49,6 +49,14 @@ def parse():
                     help="auto (= ensemble8) | ensemble8 | ensemble (7 manifest members) | ensemble4 | <member name>; "
                          "suffix -resident: start from decoded pixels in HBM")
     ap.add_argument("--shard", default="images", choices=["images", "members", "hybrid"])
+    ap.add_argument("--precision", default=None, choices=["fast", "strict"],
+                    help="fast (default): fp16 storage; strict: fp32 storage + fp32 matrix arithmetic (every member logit within 1e-3 "
+                         "of the fp32 oracle).  The default run times the strict mode too and reports it under detail.strict_precision")
+    ap.add_argument("--distinct-batches", type=int, default=20,
+                    help="the steps cycle through this many distinct batches of synthetic JPEGs (20 x 256 = 5 120 distinct files: "
+                         "BASELINE config 5's 5 000-image set)")
+    ap.add_argument("--no-strict-leg", action="store_true")
+    ap.add_argument("--no-batch-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batches", type=int, default=3, help="timed CPU batches of 128 images (after one discarded)")
     ap.add_argument("--no-resident-leg", action="store_true")
@@ -121,10 +129,13 @@ def cpu_baseline(wl, timed_batches: int):
 
 
 def timed_steps(wl, dist, steps, warmup):
+    on_gpu = torch.cuda.is_available()
+
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     # pipelined steps (VIP_STEP_PIPELINE=0: join every step): step i is joined and scored after step i+1 has been forked; the step
     # left in flight is flushed INSIDE the bracket it was forked in, so the timed region holds exactly `steps` forks and `steps` joins
@@ -140,24 +151,48 @@ def timed_steps(wl, dist, steps, warmup):
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start N ranks of this script (one per GPU) as CHILD processes through
+    torch.distributed.run and relay their output - rank 0's JSON line goes to stdout as it is.  Runs before anything in this process
+    has touched the GPU (no torch.cuda call yet), and never replaces the process (no exec)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note(f"--gpus {n} without WORLD_SIZE: launching {n} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    # `--workload fake`: the launcher / rendezvous / timing / JSON plumbing of this file on CPU tensors over gloo, no kernels
+    # (tests/test_bench_launcher_cpu.py) - never a measurement
+    fake = a.workload == "fake"
+    if not torch.cuda.is_available() and not fake:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one rank per GPU; VIP_DIST_BACKEND=gloo lets several ranks share a card (a rehearsal of the N > 1 control flow on a
     # one-GPU box - RCCL itself refuses two ranks on one device)
-    backend = os.environ.get("VIP_DIST_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
+    backend = "gloo" if fake else os.environ.get("VIP_DIST_BACKEND", "nccl")
+    dev_index = 0
+    if not fake:
+        dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -171,12 +206,38 @@ def main():
     import vipcup_amd  # noqa: F401
     from vipcup_amd import workloads
 
+    if fake:
+        wl = workloads.FakeWorkload(a.batch, rank, world)
+        dt = timed_steps(wl, dist, a.steps, a.warmup)
+        if rank == 0:
+            print(json.dumps({"metric": "images/sec (200x200, full ensemble)", "value": a.batch * world * a.steps / dt, "unit": "images/sec",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "fake",
+                              "config": wl.config(), "roofline": None, "cpu_baseline": None,
+                              "detail": {"checksum": float(wl.scores.sum()), "steps_seen": wl.steps_seen}}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    from vipcup_amd import ensemble, ops, zoo
     name = a.workload if a.workload != "auto" else workloads.DEFAULT
+    mode = a.precision or ops.PRECISION
     if rank == 0:
-        note(f"building workload {name} (members + bias calibration)")
-    wl = workloads.build(name, batch=a.batch, rank=rank, world=world, shard=a.shard)
+        note(f"building workload {name} ({mode}: members" + (" + bias calibration)" if mode == "fast" else ")"))
+    costs, models = None, None
+    if a.shard == "hybrid" and world > 1:
+        # the hybrid plan needs ms / image per member: measured HERE (rank 0, one serial pass, broadcast), every rank resident with
+        # every member for the measurement; the plan then says which of them a rank keeps
+        from tools.make_synth import synth_jpeg
+        keys = workloads.member_list(name[:-len("-resident")] if name.endswith("-resident") else name)
+        models = [zoo.build_member(k, precision=mode) for k in keys]
+        costs = ensemble.measure_costs(models, [synth_jpeg(i) for i in range(min(a.batch, 64))], dist, rank)
+        if rank == 0:
+            note("hybrid plan from measured ms/image: " + ", ".join(f"{k} {c:.4f}" for k, c in zip(keys, costs)))
+    wl = workloads.build(name, batch=a.batch, rank=rank, world=world, shard=a.shard, precision=mode, costs=costs,
+                         distinct_batches=a.distinct_batches, models=models)
     if rank == 0:
-        note(f"timing {a.warmup} + {a.steps} steps")
+        note(f"timing {a.warmup} + {a.steps} steps over {len(wl.jpeg_batches)} distinct batches")
     dt = timed_steps(wl, dist, a.steps, a.warmup)
     if rank == 0:
         note(f"{a.batch * world * a.steps / dt:.0f} images/s, {dt / a.steps * 1e3:.2f} ms/step")
@@ -184,11 +245,49 @@ def main():
     # the metric's "inputs already resident in HBM" form of the same step, for the record (never `value` here)
     resident = None
     if not wl.resident and not a.no_resident_leg:
-        wr = workloads.Workload(wl.name, wl.members, a.batch, rank, world, a.shard, resident=True, jpegs=wl.jpegs, models=wl.models)
+        wr = workloads.Workload(wl.name, wl.members, a.batch, rank, world, a.shard, resident=True, jpegs=wl.jpegs, models=wl.models,
+                                precision=mode, costs=costs)
         wr.member_streams = wl.member_streams                                # same resident members, same stream assignment
         dtr = timed_steps(wr, dist, a.steps, 1)
         resident = {"images_per_sec": a.batch * world * a.steps / dtr, "ms_per_step": dtr / a.steps * 1e3,
                     "input": "decoded RGB u8 resident in HBM (no Huffman / H2D / IDCT in the step)"}
+
+    # the price of the stated tolerance, driver-timed: the same step in STRICT precision (fp32 storage, f32 MFMA)
+    strict = None
+    if mode == "fast" and not a.no_strict_leg and a.shard == "images":
+        if rank == 0:
+            note("strict-precision leg: building fp32 members")
+        ws = workloads.build(name, batch=a.batch, rank=rank, world=world, shard=a.shard, precision="strict", jpegs=wl.jpeg_batches)
+        k_strict = max(3, min(a.steps, 5))
+        dts = timed_steps(ws, dist, k_strict, 1)
+        strict = {"images_per_sec": a.batch * world * k_strict / dts, "ms_per_step": dts / k_strict * 1e3, "steps": k_strict,
+                  "arithmetic": "fp32 storage, v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak), libm activations",
+                  "parity": "every member's calibrated logit and logit(ensemble mean) within 1e-3 of the fp32 oracle "
+                            "(tests/test_gpu_strict.py)"}
+        if rank == 0:
+            note(f"strict: {strict['images_per_sec']:.0f} images/s, {strict['ms_per_step']:.2f} ms/step")
+        ws.close()
+        del ws
+        torch.cuda.empty_cache()
+
+    # batch sweep for the default step (the deep stages run at M = B x 49 rows: larger batches fill the chip better)
+    sweep = None
+    if not a.no_batch_sweep and world == 1 and not wl.resident:
+        sweep = {str(a.batch): {"images_per_sec": a.batch * a.steps / dt, "ms_per_step": dt / a.steps * 1e3}}
+        for bsz in (512, 1024):
+            if bsz == a.batch:
+                continue
+            flat = [j for b in wl.jpeg_batches for j in b]
+            if len(flat) < bsz:
+                continue
+            batches = [flat[i:i + bsz] for i in range(0, len(flat) - bsz + 1, bsz)]
+            wb = workloads.Workload(wl.name, wl.members, bsz, rank, world, a.shard, jpegs=batches, models=wl.models, precision=mode)
+            dtb = timed_steps(wb, dist, 5, 2)
+            sweep[str(bsz)] = {"images_per_sec": bsz * 5 / dtb, "ms_per_step": dtb / 5 * 1e3}
+            note(f"batch {bsz}: {sweep[str(bsz)]['images_per_sec']:.0f} images/s")
+            wb.close()
+            del wb
+            torch.cuda.empty_cache()
 
     roof, peaks = None, None
     if rank == 0:
@@ -213,13 +312,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16",
+            "dtype": "f32" if mode == "strict" else "f16",
             "data": "synthetic",
             "config": wl.config(),
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        detail = {"kernel_families": wl.extra(), "resident_input_variant": resident,
+        detail = {"kernel_families": wl.extra(), "resident_input_variant": resident, "strict_precision": strict,
+                  "batch_sweep": sweep,
                   "peaks": {"vendor": {"mfma_f16_tflops": PEAK_MFMA_F16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS},
                             "measured_on_box": {k: round(v, 1) for k, v in peaks.items() if k.endswith("_measured")}}}
         if world > 1:

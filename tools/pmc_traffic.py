@@ -37,5 +37,10 @@ for fam in FAMILIES:
                 "hbm_bytes_per_launch": rd + wr}
 out["_note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python bench.py --steps 2 --warmup 1`, " \
                "VIP_STREAMS=1; FETCH_SIZE x2 (gfx950 correction), KiB -> bytes"
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vipcup_amd  # noqa: E402,F401
+from vipcup_amd import workloads  # noqa: E402
+out["_source_digest"] = workloads.source_digest()      # bench.py reports `traffic` only from a summary of the SAME kernel sources
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -32,7 +32,13 @@
 #pragma once
 
 constexpr int G8_SLOT = 128 * 128;                 // bytes per half-tile slot
-constexpr unsigned G8_OOB = 0x80000000u;           // out-of-range voffset that survives "+ k offset" without wrapping
+// Out-of-range voffset for rows / k-tiles that do not exist (the buffer descriptor returns zeros, no traffic).  A row sentinel plus
+// an in-range k offset stays >= 2^31; row sentinel + K SENTINEL would wrap to 0 and fetch real data from offset 0, so the two are
+// combined with g8_voff() (saturating), never added.
+constexpr unsigned G8_OOB = 0x80000000u;
+__device__ __forceinline__ unsigned g8_voff(unsigned row_off, unsigned k_off) {
+    return ((row_off | k_off) & G8_OOB) ? G8_OOB : row_off + k_off;
+}
 
 template <int KIND>   // 0 = A0, 1 = B0, 2 = B1, 3 = A1 : slot order inside a buffer
 __device__ __forceinline__ char* g8_slot(char* smem, int buf) { return smem + (buf * 4 + KIND) * G8_SLOT; }
@@ -114,13 +120,13 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
     // (in range they fetched 2/nk extra bytes per tile: PMC read 1.35x the algorithmic bytes on the K = 384 layers).
     auto stageA = [&](int g, char* slot, int kt) {
         const unsigned ko = kt < nk ? (unsigned)kt * 128u : G8_OOB;
-        g8_dma(rw, slot + dma_lds[0], vA[g][0] + ko);
-        g8_dma(rw, slot + dma_lds[1], vA[g][1] + ko);
+        g8_dma(rw, slot + dma_lds[0], g8_voff(vA[g][0], ko));
+        g8_dma(rw, slot + dma_lds[1], g8_voff(vA[g][1], ko));
     };
     auto stageB = [&](int h, char* slot, int kt) {
         const unsigned ko = kt < nk ? (unsigned)kt * 128u : G8_OOB;
-        g8_dma(rx, slot + dma_lds[0], vB[h][0] + ko);
-        g8_dma(rx, slot + dma_lds[1], vB[h][1] + ko);
+        g8_dma(rx, slot + dma_lds[0], g8_voff(vB[h][0], ko));
+        g8_dma(rx, slot + dma_lds[1], g8_voff(vB[h][1], ko));
     };
     // prologue: half-tiles 0..6 = A0,B0,B1,A1 of k-tile 0 and A0,B0,B1 of k-tile 1
     auto issue_prologue = [&]() {

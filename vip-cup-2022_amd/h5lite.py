@@ -72,6 +72,8 @@ class Dataset:
             elif t == 0xC:
                 k, v = f._attribute(off)
                 self.attrs[k] = v
+            elif t == 0x15:
+                f._refuse_dense_attributes(off, name)
         if layout is None or self.dtype is None:
             raise H5Error(f"{name}: dataset without a layout or datatype message")
         self._layout, self._filters = layout, filters or []
@@ -175,6 +177,8 @@ class Group:
             elif t == 0xC:
                 k, v = f._attribute(off)
                 self.attrs[k] = v
+            elif t == 0x15:
+                f._refuse_dense_attributes(off, name)
 
     def keys(self) -> List[str]:
         return list(self._links)
@@ -231,6 +235,17 @@ class File(Group):
         Group.__init__(self, self, "/", self._messages(root_addr))
 
     # ---- object headers ---------------------------------------------------------------------------------------------
+    def _refuse_dense_attributes(self, off: int, name: str):
+        """Attribute Info message (0x15): version, flags, [max creation index], fractal-heap address, name B-tree address.  A defined heap
+        address means the object's attributes live in dense storage (more than 8 attributes, or written with libver='latest' phase-change
+        settings) - not read here.  Refuse: silently returning an object WITHOUT its layer_names / weight_names would make the Keras
+        loader fall back to 'every dataset in the tree' under the wrong keys."""
+        r = self.r
+        fl = r.u(off + 1, 1)
+        p = off + 2 + (2 if fl & 1 else 0)
+        if r.offs(p) != UNDEF:
+            raise H5Unsupported(f"{name}: dense attribute storage (fractal heap)")
+
     def _messages(self, addr: int):
         """[(type, data offset, data size, flags)] of the object header at ``addr`` (continuation blocks followed)"""
         r = self.r
@@ -248,6 +263,7 @@ class File(Group):
             size0 = r.u(p, szb)
             p += szb
             blocks = [(p, size0)]
+            seen = {p}
             track = bool(flags & 0x04)
             while blocks:
                 p, n = blocks.pop(0)
@@ -259,6 +275,9 @@ class File(Group):
                         coff, clen = r.offs(p), r.lens(p + r.so)
                         if r.b[coff:coff + 4] != b"OCHK":
                             raise H5Error("object header continuation without OCHK signature")
+                        if coff + 4 in seen or len(seen) > 4096:       # a continuation that points back at a block already read
+                            raise H5Error("object header continuation chain loops")
+                        seen.add(coff + 4)
                         blocks.append((coff + 4, clen - 8))
                     elif t != 0:
                         out.append((t, p, size, fl))

@@ -45,12 +45,22 @@ def main(argv=None):
                     help="how N > 1 ranks split the (member, image-shard) grid: images = every rank all members on its image shard "
                          "(MirroredStrategy's split, utils/device.py:7); members = rank r owns members r mod N and scores every "
                          "image (one model per GPU); hybrid = LPT packing by measured ms/image.  One all-gather in every mode.")
+    ap.add_argument("--precision", default=None, choices=["fast", "strict"],
+                    help="fast (default; env VIP_PRECISION): fp16 storage, the throughput path - member logits at the fp16 storage floor "
+                         "(7e-4 ... 8e-3 vs an fp32 run).  strict: fp32 storage and fp32 matrix arithmetic, what the reference's "
+                         "TensorFlow run computes in (main.py:107-109): every member's logit within 1e-3 of it, ~3.5x slower.")
+    ap.add_argument("--calibration-images", default=None, metavar="DIR",
+                    help="fast mode: a directory of JPEGs (up to 32 are read) for the bias calibration of the fp16 weights instead of the "
+                         "built-in seeded synthetic batch - use real images with real checkpoints (the correction needs typical "
+                         "per-channel input means; inputs only, no labels)")
+    ap.add_argument("--no-bias-calibration", action="store_true",
+                    help="fast mode: plain fp16 weights, no calibration pass at load time")
     a = ap.parse_args(argv)
 
     import pandas as pd
     import torch
     import vipcup_amd  # noqa: F401
-    from vipcup_amd import ensemble, zoo
+    from vipcup_amd import ensemble, ops, pipeline, zoo
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,6 +96,17 @@ def main(argv=None):
                 continue
             raise ValueError(f"manifest member {name} has no graph in vipcup_amd.zoo")
         manifest.append((name, dim, idx, key))
+    mode = a.precision or ops.PRECISION
+    calib = None
+    if a.calibration_images and mode == "fast" and not a.no_bias_calibration:
+        files = sorted(glob(os.path.join(a.calibration_images, "*.jpg")) + glob(os.path.join(a.calibration_images, "*.jpeg")) +
+                       glob(os.path.join(a.calibration_images, "*.JPG")))[:32]
+        if not files:
+            raise ValueError(f"--calibration-images {a.calibration_images}: no *.jpg / *.jpeg files")
+        calib = pipeline.decode_jpegs([open(f, "rb").read() for f in files])
+        if rank == 0:
+            print(f"> BIAS CALIBRATION on {len(files)} images from {a.calibration_images}")
+    build = dict(bias_calibration=not a.no_bias_calibration, precision=mode, calibration_batch=calib)
     plan = ensemble.ShardPlan("members" if a.shard == "members" else "images", len(manifest), world)
     mine = {m for ms in plan.units[rank].values() for m in ms}   # members mode: a rank loads only the members it owns
     members = []
@@ -99,14 +120,14 @@ def main(argv=None):
             members.append((spec, None))
             continue
         if ckpts:
-            folds = [zoo.construct(spec, zoo.match_variable_names(spec, zoo.read_checkpoint(c))) for c in ckpts]
+            folds = [zoo.construct(spec, zoo.match_variable_names(spec, zoo.read_checkpoint(c)), **build) for c in ckpts]
         elif a.synthetic:
-            folds = [zoo.build_member(key)[1]]
+            folds = [zoo.build_member(key, **build)[1]]
         else:
             raise ValueError(f"no checkpoints under ckpts/{name}/ckpt (pass --synthetic for seeded synthetic weights)")
         members.append((spec, zoo.FoldMean(folds)))                # mean over folds, main.py:121
         if rank == 0:
-            print(f"> MODEL({len(members)}): {name} | DIM: {dim} | folds: {len(folds)}")
+            print(f"> MODEL({len(members)}): {name} | DIM: {dim} | folds: {len(folds)} | precision: {mode}")
 
     def jpegs_for(lo, hi):
         out = []

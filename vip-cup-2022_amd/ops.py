@@ -149,6 +149,8 @@ class calibration:
     def __exit__(self, *exc):
         global _CALIB, _UNFUSED
         _CALIB, _UNFUSED = self._old
+        if os.environ.get("VIP_OFFSET_CALIBRATION", "0") != "1":
+            drop_exact_weights()            # nothing will read the twins: do not let a caller without zoo.calibrate() leak them
         return False
 
 
@@ -208,13 +210,14 @@ def _bias_correct(cw: "ConvWeight", x_eff: torch.Tensor):
     k = cw.kh * cw.kw * cw.cin_g
     cog = cw.cout // cw.groups
     taps = cw.kh * cw.kw
-    w2 = torch.cat([cw.w[:, :k].reshape(cw.cout, taps, cw.cin_g), cw.err[:, :k].to(torch.float16).reshape(cw.cout, taps, cw.cin_g)], 2)
-    w2 = w2.reshape(cw.cout, 2 * k)
-    if (2 * k) % 8:
-        w2 = torch.cat([w2, w2.new_zeros(cw.cout, 8 - (2 * k) % 8)], 1)
-    cw.exact = ConvWeight(w=w2.contiguous(), bias=cw.bias, kh=cw.kh, kw=cw.kw, cin_g=2 * cw.cin_g, cout=cw.cout, groups=cw.groups,
-                          alg_cin_g=cw.alg_cin_g)
-    _EXACT_REG.append(cw)
+    if os.environ.get("VIP_OFFSET_CALIBRATION", "0") == "1":       # the K-doubled twin is only read by zoo.calibrate's opt-in second pass
+        w2 = torch.cat([cw.w[:, :k].reshape(cw.cout, taps, cw.cin_g), cw.err[:, :k].to(torch.float16).reshape(cw.cout, taps, cw.cin_g)], 2)
+        w2 = w2.reshape(cw.cout, 2 * k)
+        if (2 * k) % 8:
+            w2 = torch.cat([w2, w2.new_zeros(cw.cout, 8 - (2 * k) % 8)], 1)
+        cw.exact = ConvWeight(w=w2.contiguous(), bias=cw.bias, kh=cw.kh, kw=cw.kw, cin_g=2 * cw.cin_g, cout=cw.cout, groups=cw.groups,
+                              alg_cin_g=cw.alg_cin_g)
+        _EXACT_REG.append(cw)
     e = cw.err[:, :k].reshape(cw.groups, cog, cw.kh * cw.kw, cw.cin_g)
     corr = (e * mu.reshape(cw.groups, 1, 1, cw.cin_g)).sum((2, 3)).reshape(cw.cout)
     cw.bias = corr if cw.bias is None else (cw.bias + corr)

@@ -21,10 +21,10 @@ from . import zoo
 
 DEFAULT = "ensemble8"
 
-# ms per 256 images of each member alone on one MI355X (profiles/r01_members_v5.log; ViT-S from r01_configs_attention_v5.log):
-# the a-priori cost vector of the hybrid ShardPlan when nothing has been measured in-process yet
-MEMBER_MS_256 = {"convnext_tiny_in22k": 16.8, "gcvit_tiny": 9.3, "efficientnet_v1b4": 8.0, "resnest50": 6.5, "resnet_rs50": 6.2,
-                 "eca_nfnet_l0": 5.6, "efficientnet_v2t": 4.9, "vit_small_patch16_224": 5.0, "vit_tiny_patch16_224": 2.2}
+# A-priori relative cost of a member for the hybrid ShardPlan: its algorithmic GMAC / image (zoo.MEMBERS).  Only the fallback when a
+# workload is built without measured costs - bench.py / main.py measure ms per image in-process (ensemble.measure_costs on rank 0,
+# broadcast) and pass them in, so the plan follows the kernels as they are, not a table from an earlier round.
+MEMBER_MS_256: Dict[str, float] = {}
 
 
 class KernelProfile:
@@ -76,22 +76,35 @@ def kernel_family(name: str) -> str:
 
 class Workload:
     def __init__(self, name: str, members: List[str], batch: int, rank: int, world: int, shard: str = "images",
-                 resident: bool = False, jpegs: Optional[Sequence[bytes]] = None, models=None):
+                 resident: bool = False, jpegs: Optional[Sequence[bytes]] = None, models=None, precision: Optional[str] = None,
+                 costs: Optional[Sequence[float]] = None, distinct_batches: int = 1):
+        """``jpegs``: one batch of JPEG byte strings, or a list of batches (lists) the steps cycle through; default: ``distinct_batches``
+        batches of the synthetic generator (images 0 .. distinct_batches * batch - 1: with 20 batches of 256 the timed steps walk the
+        5 120 distinct files of BASELINE config 5's "5 000-image set").  ``precision``: "fast" | "strict" (None = ops.PRECISION).
+        ``costs``: measured ms / image per member for the hybrid plan (identical on every rank)."""
         self.name, self.batch, self.rank, self.world, self.members = name, batch, rank, world, members
         self.shard, self.resident = shard, resident
-        costs = [MEMBER_MS_256.get(m, 10.0 * zoo.MEMBERS[m].gmac_per_image / 4.0) for m in members]
+        self.precision = precision or ops.PRECISION
+        if costs is None:
+            costs = [MEMBER_MS_256.get(m, zoo.MEMBERS[m].gmac_per_image) for m in members]
         self.plan = ensemble.ShardPlan(shard, len(members), world, costs)
         if models is None:
             mine = sorted({m for ms in self.plan.units[rank].values() for m in ms})
-            built = {m: zoo.build_member(members[m]) for m in mine}          # only what this rank's plan names is resident
+            built = {m: zoo.build_member(members[m], precision=self.precision) for m in mine}   # only what this rank's plan names is resident
             models = [built.get(m, (zoo.MEMBERS[members[m]], None)) for m in range(len(members))]
         self.models = models
-        # one synthetic batch (SURVEY.md section 8(d) generator), the same bytes for every image-shard: JPEG byte strings in host RAM
+        # synthetic batches (SURVEY.md section 8(d) generator), the same bytes for every image-shard: JPEG byte strings in host RAM
         if jpegs is None:
             from tools.make_synth import synth_jpeg
-            jpegs = [synth_jpeg(i) for i in range(batch)]
-        assert len(jpegs) == batch
-        self.jpegs = list(jpegs)
+            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:       # PIL releases the GIL while encoding
+                flat = list(ex.map(synth_jpeg, range(batch * max(1, distinct_batches))))
+            jpegs = [flat[i:i + batch] for i in range(0, len(flat), batch)]
+        if len(jpegs) and isinstance(jpegs[0], (bytes, bytearray, memoryview)):
+            jpegs = [list(jpegs)]
+        self.jpeg_batches = [list(b) for b in jpegs]
+        assert self.jpeg_batches and all(len(b) == batch for b in self.jpeg_batches)
+        self.jpegs = self.jpeg_batches[0]              # the batch the CPU baseline and the resident variant use
+        self._next_idx = 0
         self.scores = None
         self.member_streams = ensemble.MemberStreams(ensemble.default_streams())
         self._serial = ensemble.MemberStreams(1)
@@ -107,7 +120,10 @@ class Workload:
 
     # ---- input stage -------------------------------------------------------------------------------------------------
     def _host_stage(self):
-        return pipeline.entropy_decode(self.jpegs, pinned=True)
+        """Huffman-decode the next batch of the cycle (runs on the one read-ahead thread, so the counter needs no lock)"""
+        raws = self.jpeg_batches[self._next_idx % len(self.jpeg_batches)]
+        self._next_idx += 1
+        return pipeline.entropy_decode(raws, pinned=True)
 
     def _next_batch(self) -> pipeline.DecodedBatch:
         """decoded RGB u8 of the next image-shard: from HBM (resident) or through the JPEG path with one batch of read-ahead"""
@@ -192,8 +208,10 @@ class Workload:
         par = {"images": f"image-parallel dp{self.world}", "members": f"member-parallel mp{self.world} (rank r owns members r mod N)",
                "hybrid": f"hybrid LPT over {len(self.members)}x{self.world} (member, image-shard) units"}[self.shard]
         return {"workload": self.name + ("-resident" if self.resident else ""), "members": self.members,
+                "precision": self.precision, "distinct_images": len(self.jpeg_batches) * self.batch,
                 "batch_per_shard": self.batch, "global_batch": self.batch * self.world,
-                "input": inp + " -> bicubic resize + /255 per member resolution -> fp16 NHWC",
+                "input": inp + " -> bicubic resize + /255 per member resolution -> "
+                         + ("fp32" if self.precision == "strict" else "fp16") + " NHWC",
                 "parallelism": par + ", one all-gather of scores", "shard": self.shard,
                 "member_streams": self.member_streams.n}
 
@@ -255,6 +273,47 @@ class Workload:
                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])}
 
 
+class FakeWorkload:
+    """`bench.py --workload fake`: the step / flush / exchange protocol of ``Workload`` on CPU tensors with no kernels - each rank's
+    "scores" are its rank number, exchanged with ONE all-gather per step like the real payloads.  Exists so that bench.py's launcher,
+    rendezvous, barrier / max-over-ranks timing and JSON line can be exercised at world > 1 without a GPU; never a measurement."""
+
+    def __init__(self, batch: int, rank: int, world: int):
+        self.batch, self.rank, self.world = batch, rank, world
+        self.scores, self._pending, self.steps_seen = None, None, 0
+
+    def _exchange(self, dist):
+        mine = torch.full((self.batch,), float(self.rank + 1))
+        if dist is None or self.world == 1:
+            return mine
+        out = torch.empty((self.world * self.batch,))
+        dist.all_gather_into_tensor(out, mine)
+        return out
+
+    def step(self, dist=None, serial=False, pipelined=False):
+        self.steps_seen += 1
+        if not pipelined:
+            self.scores = self._exchange(dist)
+            return self.scores
+        prev, self._pending = self._pending, True
+        if prev:
+            self.scores = self._exchange(dist)
+            return self.scores
+        return None
+
+    def flush(self, dist=None):
+        if self._pending:
+            self._pending = None
+            self.scores = self._exchange(dist)
+        return self.scores
+
+    def close(self):
+        pass
+
+    def config(self):
+        return {"workload": "fake", "batch_per_shard": self.batch, "global_batch": self.batch * self.world}
+
+
 class _NoExchange:
     """stand-in process group for the instrumented (single-rank) step of a multi-rank run: the gather is skipped"""
 
@@ -273,10 +332,27 @@ def _pmc_traffic(fam: str):
     key = "pwk_gemm_kernel" if fam == "pwk_*" else fam
     for path in sorted(glob.glob(os.path.join(root, "r*_hbm_traffic_pmc.json")), reverse=True):
         try:
-            return json.load(open(path))[key]["hbm_bytes_per_launch"]
+            d = json.load(open(path))
+            # only a PMC summary taken from THIS kernel build counts: the summary records the library's source digest
+            # (tools/pmc_traffic.py), a stale one is reported as null rather than passed off as current
+            if d.get("_source_digest") != source_digest():
+                return None
+            return d[key]["hbm_bytes_per_launch"]
         except Exception:
             continue
     return None
+
+
+def source_digest() -> str:
+    """sha256 over the kernel sources (csrc/*, include/vipcup_hip.h): ties a committed PMC summary to the build it was measured on"""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    hsh = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(here, "csrc", "*")) + [os.path.join(os.path.dirname(here), "include", "vipcup_hip.h")]):
+        with open(path, "rb") as f:
+            hsh.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return hsh.hexdigest()[:16]
 
 
 def measure_peaks(ms_budget: float = 50.0) -> Dict[str, float]:
@@ -317,16 +393,13 @@ def measure_peaks(ms_budget: float = 50.0) -> Dict[str, float]:
     return {"hbm_gbs_measured": 2.0 * nbytes / (t_copy * 1e-3) / 1e9, "mfma_tflops_measured": flops.value / (t_mfma * 1e-3) / 1e12}
 
 
+def member_list(name: str) -> List[str]:
+    return list({"ensemble": zoo.ENSEMBLE, "ensemble8": zoo.ENSEMBLE8, "ensemble4": zoo.ENSEMBLE4}.get(name, [name]))
+
+
 def build(name: str, batch: int, rank: int = 0, world: int = 1, shard: str = "images", resident: bool = False,
-          jpegs: Optional[Sequence[bytes]] = None) -> Workload:
+          jpegs: Optional[Sequence[bytes]] = None, precision: Optional[str] = None, costs: Optional[Sequence[float]] = None,
+          distinct_batches: int = 1, models=None) -> Workload:
     if name.endswith("-resident"):
         name, resident = name[:-len("-resident")], True
-    if name == "ensemble":
-        members = zoo.ENSEMBLE
-    elif name == "ensemble8":
-        members = zoo.ENSEMBLE8
-    elif name == "ensemble4":
-        members = zoo.ENSEMBLE4
-    else:
-        members = [name]
-    return Workload(name, list(members), batch, rank, world, shard, resident, jpegs)
+    return Workload(name, member_list(name), batch, rank, world, shard, resident, jpegs, models, precision, costs, distinct_batches)
