@@ -9,20 +9,33 @@ from PIL import Image
 
 from oracle import ops_ref as R
 
-# BASELINE.json north_star: |z_hip - z_ref| <= 1e-3 on the sigmoid logit.
+# BASELINE.json north_star: |z_hip - z_ref| <= 1e-3 on the sigmoid logit - every member's and the ensemble score's.
 TOL_NORTH_STAR = 1e-3
-# Per-member ceilings on the CALIBRATED logit (tests/gen_synth_heads.py: the head reads the top principal direction of the oracle's
-# features and is scaled to a logit spread of 1.5, which multiplies a relative feature error by |w||f| = 12 ... 78, /tmp-measured in
-# DESIGN.md section 4).  What the HIP path delivers is the fp16-STORAGE floor: tests/diag_gpu_vs_emul.py runs the same graph on the
-# CPU with fp32 arithmetic and only the operator outputs rounded to fp16 - its error equals the GPU's for every member (e.g.
-# EfficientNetV1-B4 4.4e-3 rms emulated vs 4.3e-3 on the GPU), i.e. the kernels add nothing to it.  Members whose ceiling is above
-# 1e-3 do NOT meet the north-star tolerance member by member; the test reports which, and asserts the ceiling (max over <= 128 images).
+# Two precision modes, two sets of bounds:
+#
+# * STRICT (fp32 storage, f32 MFMA; tests/test_gpu_strict.py, the strict variants below): TOL_NORTH_STAR is asserted as it stands, on every
+#   member's calibrated logit, on logit(ensemble mean), on the synthetic set and on the photographs, absolute.  Measured: <= 5e-5.
+#
+# * FAST (fp16 storage, the throughput path bench.py's `value` is quoted on): the member logits sit at the fp16-STORAGE floor of each
+#   graph (tests/diag_gpu_vs_emul.py: a CPU emulation with fp32 arithmetic and only the operator outputs rounded to fp16 reproduces the
+#   GPU's error for every member), amplified by the calibrated synthetic heads (tests/gen_synth_heads.py: |w||f| = 12 ... 78).  The two
+#   members that meet the north star are held to it; the other five are NOT within 1e-3 in this mode - their ceilings below are their
+#   measured floors (max over <= 128 images), stated so that a regression shows, not to claim the tolerance.
 MEMBER_CEILING = {
-    "eca_nfnet_l0": 1.5e-3, "resnet_rs50": 2.5e-3, "convnext_tiny_in22k": 1.5e-3, "resnest50": 4.0e-3,
-    "gcvit_tiny": 7.0e-3, "efficientnet_v2t": 1.0e-2, "efficientnet_v1b4": 1.8e-2,
+    "eca_nfnet_l0": TOL_NORTH_STAR, "convnext_tiny_in22k": TOL_NORTH_STAR,        # measured 7.0e-4 / 8.1e-4 on 64 images
+    "resnet_rs50": 2.5e-3, "resnest50": 4.0e-3, "gcvit_tiny": 7.0e-3, "efficientnet_v2t": 1.0e-2, "efficientnet_v1b4": 1.8e-2,
     "vit_tiny_patch16_224": 4.0e-3, "vit_small_patch16_224": 4.0e-3,
 }
-TOL_ENSEMBLE_PROB = 1e-3   # the ensemble-mean probability main.py thresholds at 0.487 (uncorrelated member errors average down)
+# fast mode, photographs (off the bias-calibration distribution; logits reach +-20): ABSOLUTE |dz| ceilings, measured
+# (profiles/r02_parity_gpu.log): the relative form max(1, |z|/3) used to hide these
+MEMBER_CEILING_PHOTO_ABS = {
+    "eca_nfnet_l0": 3.0e-3, "convnext_tiny_in22k": 2.0e-3, "resnet_rs50": 6.0e-3, "resnest50": 8.0e-3, "gcvit_tiny": 1.2e-2,
+    "efficientnet_v2t": 3.5e-2, "efficientnet_v1b4": 3.0e-2, "vit_tiny_patch16_224": 8.0e-3, "vit_small_patch16_224": 8.0e-3,
+}
+TOL_ENSEMBLE_PROB = 1e-3   # fast mode: the ensemble-mean PROBABILITY main.py thresholds at 0.487 (uncorrelated member errors average down)
+# fast mode: logit(ensemble mean) - the north-star axis; d logit = dp / (p (1 - p)) ~ 4 dp near the threshold.  Measured 1.4e-3 (7 / 8
+# members), 4.8e-3 (config 4's four): fast mode does NOT meet 1e-3 on this axis either; strict mode does.
+FAST_ENSEMBLE_LOGIT_CEILING = {"ensemble": 2.5e-3, "ensemble8": 2.5e-3, "ensemble4": 6.0e-3}
 
 _CACHE = {}
 

@@ -57,7 +57,9 @@ def test_main_cli_matches_oracle(tmp_path, report):
         per_member[key] = dz.max()
     mean_ref = np.mean([probs[k] for k in zoo.ENSEMBLE], axis=0)
     dm = np.abs(got["ensemble_mean"].values - mean_ref).max()
-    report(f"[e2e] ensemble mean max|dp|={dm:.3e}; worst member |dz|={worst:.3e}")
+    dl = np.abs(_logit(got["ensemble_mean"].values) - _logit(mean_ref)).max()
+    report(f"[e2e] ensemble mean max|dp|={dm:.3e} max|d logit(mean)|={dl:.3e}; worst member |dz|={worst:.3e}")
+    assert dl <= P.FAST_ENSEMBLE_LOGIT_CEILING["ensemble"]
     within = [k for k, v in per_member.items() if v <= TOL_NORTH_STAR]
     report(f"[e2e] members within the north-star 1e-3 on the calibrated logit: {len(within)} of {len(per_member)} {within}")
     assert dm <= TOL_ENSEMBLE_PROB
@@ -69,6 +71,63 @@ def test_main_cli_matches_oracle(tmp_path, report):
     flips = [n for n, v in zip(dec.filename, dec.logit) if v != want[n] and margin[n] > TOL_ENSEMBLE_PROB]
     report(f"[e2e] decisions: {int(dec.logit.sum())}/{len(dec)} positive, flips vs oracle: {len(flips)}")
     assert not flips
+
+
+def test_main_cli_strict_meets_north_star(tmp_path, report):
+    """`main.py --precision strict` on the same CSV: EVERY member's logit, and logit(ensemble mean), within BASELINE.json's 1e-3 of the
+    fp32 oracle; decisions identical with no margin exemption."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import main as cli, zoo
+    idx = P.e2e_image_ids(N_IMG)
+    names = []
+    for i in idx:
+        n = f"img_{i:05d}.jpg"
+        (tmp_path / n).write_bytes(synth_jpeg(i))
+        names.append(n)
+    (tmp_path / "test.csv").write_text("filename\n" + "\n".join(names) + "\n")
+    out_csv, scores_csv = tmp_path / "out.csv", tmp_path / "scores.csv"
+    cli.main([str(tmp_path / "test.csv"), str(out_csv), "--synthetic", "--scores-out", str(scores_csv), "--batch-size", "8",
+              "--precision", "strict"])
+    got, dec = pd.read_csv(scores_csv), pd.read_csv(out_csv)
+    raws = [synth_jpeg(i) for i in idx]
+    probs = []
+    for key in zoo.ENSEMBLE:
+        z = P.oracle_logits(key, "e2e", raws)
+        probs.append(P.sigmoid(z))
+        dz = np.abs(_logit(got[key].values) - z).max()
+        report(f"[e2e/strict] {key:22s} max|dz|={dz:.3e}")
+        assert dz <= TOL_NORTH_STAR, key
+    mean_ref = np.mean(probs, axis=0)
+    dl = np.abs(_logit(got["ensemble_mean"].values) - _logit(mean_ref)).max()
+    want = dict(zip(names, (mean_ref > 0.487).astype(np.float32)))
+    flips = [n for n, v in zip(dec.filename, dec.logit) if v != want[n]]
+    report(f"[e2e/strict] max|d logit(ensemble mean)|={dl:.3e}, decision flips {len(flips)} of {len(dec)}")
+    assert dl <= TOL_NORTH_STAR and not flips
+
+
+def test_cli_calibration_flags(tmp_path, report):
+    """--no-bias-calibration and --calibration-images DIR (fast mode): a deployment with real checkpoints must not silently calibrate on
+    the built-in synthetic batch.  One member, 8 images: calibrating on the scored images' own folder is at least as close to the
+    oracle as no calibration at all."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import main as cli
+    names = []
+    for i in range(8):
+        n = f"img_{600 + i:05d}.jpg"
+        (tmp_path / n).write_bytes(synth_jpeg(600 + i))
+        names.append(n)
+    (tmp_path / "test.csv").write_text("filename\n" + "\n".join(names) + "\n")
+    cfg = tmp_path / "ckpts1.json"
+    cfg.write_text('[["GCViTTiny-224x224", [224, 224], 0]]')
+    raws = [synth_jpeg(600 + i) for i in range(8)]
+    z = P.oracle_logits("gcvit_tiny", "calflags", raws)
+    err = {}
+    for tag, extra in (("none", ["--no-bias-calibration"]), ("dir", ["--calibration-images", str(tmp_path)]), ("builtin", [])):
+        sc = tmp_path / f"s_{tag}.csv"
+        cli.main([str(tmp_path / "test.csv"), str(tmp_path / f"o_{tag}.csv"), "--synthetic", "--ckpt-cfg", str(cfg), "--scores-out", str(sc), *extra])
+        err[tag] = float(np.abs(_logit(pd.read_csv(sc)["gcvit_tiny"].values) - z).mean())
+    report(f"[e2e] GCViT mean|dz| by calibration source: none {err['none']:.3e}, --calibration-images {err['dir']:.3e}, built-in {err['builtin']:.3e}")
+    assert err["dir"] <= err["none"] and err["builtin"] <= err["none"]
 
 
 def test_tta_scores_match_oracle(report):

@@ -39,14 +39,16 @@ def test_real_photo_tiles_match_oracle(report):
         rel = dz / np.maximum(1.0, np.abs(z) / 3.0)
         report(f"[photo] {key:22s} max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e} max|dz|/max(1,|z|/3)={rel.max():.3e} "
                f"z range [{z.min():+.2f},{z.max():+.2f}]{'' if dz.max() <= P.TOL_NORTH_STAR else '   ABOVE north-star 1e-3'}")
-        if rel.max() > P.MEMBER_CEILING[key]:
-            over[key] = float(rel.max())
+        if dz.max() > P.MEMBER_CEILING_PHOTO_ABS[key]:             # absolute: no |z|-relative discount
+            over[key] = float(dz.max())
         probs_g.append(P.sigmoid(zg))
         probs_o.append(P.sigmoid(z))
-    dm = np.abs(np.mean(probs_g, 0) - np.mean(probs_o, 0)).max()
-    report(f"[photo] ensemble mean max|dp|={dm:.3e}")
-    assert not over, f"members above their ceiling on photo tiles: {over}"
-    assert dm <= P.TOL_ENSEMBLE_PROB
+    pg, po = np.mean(probs_g, 0), np.mean(probs_o, 0)
+    dm = np.abs(pg - po).max()
+    dl = np.abs(P.logit(pg) - P.logit(po)).max()
+    report(f"[photo] ensemble mean max|dp|={dm:.3e}  max|d logit(mean)|={dl:.3e}")
+    assert not over, f"members above their absolute fast-mode ceiling on photo tiles: {over}"
+    assert dm <= P.TOL_ENSEMBLE_PROB and dl <= P.FAST_ENSEMBLE_LOGIT_CEILING["ensemble"]
 
 
 @pytest.mark.parametrize("key", ["convnext_tiny_in22k", "resnest50", "gcvit_tiny", "efficientnet_v2t", "efficientnet_v1b4",
@@ -68,31 +70,34 @@ def test_member_inside_batch_256(key, report):
     assert d_self <= 2 * P.MEMBER_CEILING[key]      # two independent fp16 realisations of the same graph
 
 
+@pytest.mark.parametrize("precision", ["fast", "strict"])
 @pytest.mark.parametrize("name", ["ensemble4", "ensemble8"])
-def test_workload_scores_match_oracle(name, report):
-    """BASELINE configs 4 and 5 through the bench's own workload object: JPEG bytes in host RAM -> scores."""
+def test_workload_scores_match_oracle(name, precision, report):
+    """BASELINE configs 4 and 5 through the bench's own workload object: JPEG bytes in host RAM -> scores.  strict: logit(ensemble
+    mean) within the north-star 1e-3; fast: within its stated fp16-storage ceiling (tests/_parity.py)."""
     import vipcup_amd  # noqa: F401
     from vipcup_amd import workloads
     n = 16
     raws = [synth_jpeg(300 + i) for i in range(n)]
-    wl = workloads.build(name, batch=n, jpegs=raws)
+    wl = workloads.build(name, batch=n, jpegs=raws, precision=precision,
+                         models=[P.gpu_member(k, precision) for k in workloads.member_list(name)])
     got = wl.step().float().cpu().numpy().reshape(-1)
     got2 = wl.step().float().cpu().numpy().reshape(-1)        # the second step runs on the member streams
     probs = [P.sigmoid(P.oracle_logits(k, "wl16", raws)) for k in wl.members]
     want = np.mean(probs, 0)
     d, d2 = np.abs(got - want).max(), np.abs(got2 - want).max()
-    report(f"[{name}] {len(wl.members)} members, 16 JPEGs -> ensemble mean: max|dp| vs oracle {d:.3e} (step 2: {d2:.3e})")
-    # four members average their (uncorrelated) errors less than seven or eight do: 1.5e-3 for config 4, the north-star 1e-3 for config 5
-    tol = P.TOL_ENSEMBLE_PROB if len(wl.members) >= 7 else 1.5 * P.TOL_ENSEMBLE_PROB
-    assert d <= tol and d2 <= tol
+    dl = max(np.abs(P.logit(got) - P.logit(want)).max(), np.abs(P.logit(got2) - P.logit(want)).max())
+    report(f"[{name}/{precision}] {len(wl.members)} members, 16 JPEGs -> ensemble mean: max|dp| vs oracle {d:.3e} (step 2: {d2:.3e}), "
+           f"max|d logit(mean)| {dl:.3e}")
+    tol = P.TOL_NORTH_STAR if precision == "strict" else P.FAST_ENSEMBLE_LOGIT_CEILING[name]
+    assert dl <= tol
     # pipelined steps (what bench.py times): step i's scores come back from step i+1, the last from flush(); same images, same scores
     assert wl.step(pipelined=True) is None
     p1 = wl.step(pipelined=True).float().cpu().numpy().reshape(-1)
     p2 = wl.flush().float().cpu().numpy().reshape(-1)
     assert wl.flush() is not None                                # nothing in flight any more: the last scores again
     dp = max(np.abs(p1 - got2).max(), np.abs(p2 - got2).max())
-    report(f"[{name}] pipelined steps vs joined steps: max|dp| {dp:.3e}")
-    # same kernels on the same inputs: 0.0 in every full-suite run on this image set; another set once differed by 1.5e-4 in a long
-    # process (DESIGN section 8, open observation) - reported above, asserted at the score tolerance so that the suite stays meaningful
-    assert dp <= tol
+    report(f"[{name}/{precision}] pipelined steps vs joined steps: max|dp| {dp:.3e}")
+    # the same kernels on the same inputs in another enqueue order: bitwise equal, or it is a race
+    assert dp == 0.0
     wl.close()
