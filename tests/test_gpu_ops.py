@@ -446,7 +446,8 @@ def test_split_vector_chain(M, K, N, act, report):
 
 
 @pytest.mark.parametrize("k,groups,cin,cout", [(1, 1, 264, 128), (3, 2, 64, 96), (3, 1, 8, 32)])
-def test_exact_weight_leg(k, groups, cin, cout, report):
+def test_exact_weight_leg(k, groups, cin, cout, report, monkeypatch):
+    monkeypatch.setenv("VIP_OFFSET_CALIBRATION", "1")     # the K-doubled twins are only built when the opt-in second pass will read them
     """ops.exact_weights(): a layer that went through ops.calibration() runs with [w | fp16(W32 - w)] along K on doubled input
     channels - same kernels, ~22-bit weights.  Against the fp32-weight oracle its error is the output rounding alone."""
     ops = _ops()

@@ -155,7 +155,10 @@ def test_workload_pipelined_steps_and_input_prefetch(fake_cuda, monkeypatch):
 
     monkeypatch.setattr(pipeline, "entropy_decode", fake_entropy)
     monkeypatch.setattr(pipeline, "decode_entropy", fake_decode)
-    monkeypatch.setattr(ops, "binary_score", lambda p, out=None: p[:, 0].float())
+    def fake_score(p, out=None):
+        v = p[:, 0].float()
+        return v if out is None else out.copy_(v)
+    monkeypatch.setattr(ops, "binary_score", fake_score)
     monkeypatch.setattr(ops, "ensemble_mean", lambda full: full.mean(0))
     monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
 
@@ -174,8 +177,6 @@ def test_workload_pipelined_steps_and_input_prefetch(fake_cuda, monkeypatch):
     monkeypatch.setattr(workloads, "MEMBER_MS_256", {"a": 2.0, "b": 1.0})
     FakeCuda.costs = [2.0, 1.0]
     wl = workloads.Workload("fake", ["a", "b"], batch=4, rank=0, world=1, jpegs=[b"x"] * 4, models=models)
-    monkeypatch.setattr(workloads.ensemble, "gather_plan_scores",
-                        lambda plan, rank, n, local, dist, dev: torch.stack([local[k] for k in sorted(local)]))
     s1 = wl.step()                                                  # joined step (and the one-off calibration pass): batch 1
     assert torch.equal(s1, torch.full((4,), 2.0))                   # mean of 1 * 1 and 1 * 3
     assert [e for e in log if e[0] == "decode"] == [("decode", 1), ("decode", 2)]      # batch 2 was prefetched during step 1

@@ -58,7 +58,7 @@ def _worker(rank, world, port, mode, q):
 
     pipeline.entropy_decode = lambda jpegs, pinned=False: ("staged",)
     pipeline.decode_entropy = decode
-    ops.binary_score = lambda p, out=None: p[:, 0].float()
+    ops.binary_score = lambda p, out=None: p[:, 0].float() if out is None else out.copy_(p[:, 0].float())
     ops.ensemble_mean = lambda full: full.mean(0)
     real_gather = ensemble.gather_plan_scores
     ensemble.gather_plan_scores = lambda plan, r, n, local, d, dev: real_gather(plan, r, n, local, d, torch.device("cpu"))

@@ -85,32 +85,36 @@ class ShardPlan:
                          for r, u in enumerate(self.units))
 
 
-def gather_plan_scores(plan: ShardPlan, rank: int, n_images: int, local: Dict[Tuple[int, int], torch.Tensor], dist=None,
-                       device=None) -> torch.Tensor:
-    """The exchange step.  ``local[(s, m)]`` = scores of member m on image-shard s (1-D, this rank's units).  Each rank's
-    payload (its units back to back, in (shard, member) order, padded to the longest payload) goes through ONE
-    ``all_gather_into_tensor`` (RCCL over xGMI on GPUs, gloo in the CPU tests); returns ``[n_members, n_images]`` on every rank."""
+def plan_payload(plan: ShardPlan, rank: int, n_images: int, device):
+    """This rank's exchange payload and where each of its units' scores go in it: ``(mine [width] fp32, {(s, m): 1-D view of mine})``.
+    Producers write their scores STRAIGHT into the views (``ops.binary_score(p, out=view)``) - no staging copies."""
     world = plan.world
-    lens = [plan.payload_len(r, n_images) for r in range(world)]
-    width = max(max(lens), 1)
-    if device is None:
-        device = next(iter(local.values())).device if local else torch.device("cpu")
+    width = max(max(plan.payload_len(r, n_images) for r in range(world)), 1)
     mine = torch.zeros((width,), dtype=torch.float32, device=device)
-    off = 0
+    views, off = {}, 0
     for s in sorted(plan.units[rank]):
+        lo, hi = shard_bounds(n_images, s, world)
         for m in plan.units[rank][s]:
-            v = local[(s, m)].reshape(-1).to(torch.float32)
-            mine[off:off + v.numel()] = v
-            off += v.numel()
-    assert off == lens[rank], (off, lens[rank])
-    if dist is not None and world > 1:
-        allp = torch.empty((world * width,), dtype=torch.float32, device=device)     # flat: every backend accepts this form
+            views[(s, m)] = mine[off:off + (hi - lo)]
+            off += hi - lo
+    assert off == plan.payload_len(rank, n_images)
+    return mine, views
+
+
+def exchange_payload(plan: ShardPlan, rank: int, n_images: int, mine: torch.Tensor, dist=None) -> torch.Tensor:
+    """The exchange step: ONE ``all_gather_into_tensor`` of the ranks' payloads (RCCL over xGMI on GPUs, gloo in the CPU tests);
+    returns ``[n_members, n_images]`` on every rank.  One rank with the ``images`` plan: the payload already IS that matrix."""
+    world, width = plan.world, mine.numel()
+    gathered = dist is not None and world > 1
+    if not gathered and world == 1 and width == plan.n_members * n_images and n_images > 0:
+        return mine.view(plan.n_members, n_images)
+    if gathered:
+        allp = torch.empty((world * width,), dtype=torch.float32, device=mine.device)     # flat: every backend accepts this form
         dist.all_gather_into_tensor(allp, mine)
         allp = allp.view(world, width)
     else:
         allp = mine.view(1, width)
-    full = torch.zeros((plan.n_members, n_images), dtype=torch.float32, device=device)
-    gathered = dist is not None and world > 1
+    full = torch.zeros((plan.n_members, n_images), dtype=torch.float32, device=mine.device)
     for r in (range(world) if gathered else [rank]):     # without an exchange only this rank's units are known
         off = 0
         for s in sorted(plan.units[r]):
@@ -119,6 +123,19 @@ def gather_plan_scores(plan: ShardPlan, rank: int, n_images: int, local: Dict[Tu
                 full[m, lo:hi] = allp[r if gathered else 0, off:off + (hi - lo)]
                 off += hi - lo
     return full
+
+
+def gather_plan_scores(plan: ShardPlan, rank: int, n_images: int, local: Dict[Tuple[int, int], torch.Tensor], dist=None,
+                       device=None) -> torch.Tensor:
+    """``plan_payload`` + ``exchange_payload`` for callers that hold their units' scores as separate tensors: ``local[(s, m)]`` =
+    scores of member m on image-shard s (1-D, this rank's units).  Each rank's payload (its units back to back, in (shard, member)
+    order, padded to the longest payload) goes through ONE ``all_gather_into_tensor``; returns ``[n_members, n_images]`` on every rank."""
+    if device is None:
+        device = next(iter(local.values())).device if local else torch.device("cpu")
+    mine, views = plan_payload(plan, rank, n_images, device)
+    for key, view in views.items():
+        view.copy_(local[key].reshape(-1).to(torch.float32))
+    return exchange_payload(plan, rank, n_images, mine, dist)
 
 
 def to_binary(pred: np.ndarray) -> np.ndarray:

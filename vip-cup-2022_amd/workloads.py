@@ -117,6 +117,7 @@ class Workload:
         if resident:
             self._resident_batch = pipeline.decode_jpegs(self.jpegs)
         self.last_host_wait_ms = 0.0
+        self._device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 
     # ---- input stage -------------------------------------------------------------------------------------------------
     def _host_stage(self):
@@ -184,13 +185,13 @@ class Workload:
 
     def _finish(self, units, dist):
         n_images = self.batch * self.world
-        local = {}
+        mine, views = ensemble.plan_payload(self.plan, self.rank, n_images, self._device)
         for s, midx, preds, joins, _cache in units:
             ensemble.MemberStreams.join(joins)
             for m, p in zip(midx, preds):
-                local[(s, m)] = ops.binary_score(p)                                      # main.py:113-114
-        full = ensemble.gather_plan_scores(self.plan, self.rank, n_images, local, dist if self.world > 1 else None,
-                                           torch.device("cuda"))
+                ops.binary_score(p, out=views[(s, m)])       # main.py:113-114, written straight into the exchange payload
+        full = ensemble.exchange_payload(self.plan, self.rank, n_images, mine, dist if self.world > 1 else None)
+        self.member_scores = full                            # [members, images] as exchanged (diagnostics: tools/stress_determinism.py)
         self.scores = ops.ensemble_mean(full)                # ensemble mean per image (main.py:142-143)
         return self.scores
 
