@@ -334,6 +334,10 @@ int vip_mbconv_expand_dw_f16(const void* x, const void* we, const void* we_lo, c
  * vip_prob_to_score_f32: the same map applied to probabilities a model's predict() already returned (prob [B][N] -> score [B]).
  * ------------------------------------------------------------------------------------------ */
 int vip_head_prob_f32(const float* logits, float* prob, float* score, int B, int N, void* stream);
+/* The classifier activation a checkpoint's model_config names when it is not the default pairing above (Dense(classes,
+ * activation=classifier_activation | head_act), resnet_rs_model.py:474-476, gcvit models/gcvit.py:113): act 0 = linear (the logits),
+ * 1 = element-wise sigmoid for any N, 2 = softmax for any N (N = 1 -> 1.0, as Keras computes it). */
+int vip_head_act_f32(const float* logits, float* prob, int B, int N, int act, void* stream);
 int vip_prob_to_score_f32(const float* prob, float* score, int B, int N, void* stream);
 int vip_ensemble_mean_f32(const float* scores, float* mean, int M, int n, long ld, void* stream);
 

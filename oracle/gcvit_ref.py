@@ -132,11 +132,12 @@ def level(p, name, x, depth, heads, ws, keep_dims, downsample):
     return x
 
 
-def forward_features(p, x, cfg, collect=None):
+def forward_features(p, x, cfg, collect=None, first_strides=2):
     """GCViT.forward_features (models/gcvit.py:98-105): Stem -> levels -> LN"""
-    # Stem (layers/embedding.py:19-23): ZeroPad(1) -> Conv3x3/2 (bias) -> ReduceSize(keep_dim)
+    # Stem (layers/embedding.py:8-23): ZeroPad(1) -> Conv3x3/2 (bias) -> ReduceSize(keep_dim, first_strides): the constructor's
+    # `first_strides` (models/gcvit.py:47,70) is the stride of conv_down's reduction conv (feature.py:98), the proj conv is always /2
     x = R.conv2d(x, p["patch_embed/proj/kernel"], p["patch_embed/proj/bias"], 2, (1, 1, 1, 1))
-    x = reduce_size(p, "patch_embed/conv_down", x)
+    x = reduce_size(p, "patch_embed/conv_down", x, first_strides)
     if collect is not None:
         collect.append(x)
     n = len(cfg["depths"])
@@ -148,9 +149,9 @@ def forward_features(p, x, cfg, collect=None):
     return _ln(p, "norm", x)
 
 
-def forward_logits(p, x, cfg):
+def forward_logits(p, x, cfg, first_strides=2):
     """forward_head (models/gcvit.py:107-113): GAP -> Dense (pre-activation)"""
-    f = forward_features(p, x, cfg)
+    f = forward_features(p, x, cfg, first_strides=first_strides)
     return R.dense(R.global_avgpool(f), p["head/kernel"], p["head/bias"])
 
 

@@ -259,3 +259,69 @@ def test_load_model_from_keras_h5(tmp_path, report):
     d = (got - want).abs().max().item()
     report(f"[h5] load_model({spec.ckpt_name}/ckpt/0.h5): max |dp| vs the model built from the variables {d:.1e}")
     assert d <= 1e-6          # 0.0 when measured; both models are constructed (and bias-calibrated) separately
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/conda/bin/python3.9"), reason="no interpreter with h5py in this image")
+@pytest.mark.parametrize("key", ["efficientnet_v2t", "gcvit_tiny"])
+def test_load_model_variant_from_model_config(tmp_path, key, report):
+    """A FULL-MODEL .h5 whose model_config carries a non-default first_strides and a 2-class softmax head (main.py:107: load_model rebuilds
+    the graph from the file, not from the directory name; main.py:113-114: multi-class -> 1 - p[:, 0]): zoo.load_model picks the variant
+    up from the file and the predictions match the oracle graph built with the same arguments (models/gcvit/models/gcvit.py:47,113;
+    kecam efficientnet_v2.py:111-125)."""
+    import json
+    import subprocess
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ensemble, pipeline, zoo
+    spec = zoo.MEMBERS[key]
+    params = zoo.build_params(key, calibrated=False)
+    g = torch.Generator().manual_seed(77)
+    feat = params[f"{spec.head}/kernel"].shape[0]
+    params[f"{spec.head}/kernel"] = torch.randn(feat, 2, generator=g) * (3.0 / feat ** 0.5)       # a 2-class head with a visible spread
+    params[f"{spec.head}/bias"] = torch.tensor([0.1, -0.2])
+    hw = spec.input_hw
+    if key == "gcvit_tiny":
+        cfg = {"class_name": "Functional", "config": {"name": "gcvit_tiny", "layers": [
+            {"class_name": "InputLayer", "config": {"batch_input_shape": [None, hw, hw, 3], "name": "input_1"}},
+            {"class_name": "gcvit>Stem", "config": {"name": "patch_embed", "dim": 64, "first_strides": 1}},
+            {"class_name": "Dense", "config": {"name": "head", "units": 2, "activation": "softmax"}}]}}
+    else:
+        cfg = {"class_name": "Functional", "config": {"name": "EfficientNetV2T", "layers": [
+            {"class_name": "InputLayer", "config": {"batch_input_shape": [None, hw, hw, 3], "name": "input_1"}},
+            {"class_name": "Conv2D", "config": {"name": "stem_conv", "strides": [1, 1], "filters": 24}},
+            {"class_name": "Dense", "config": {"name": "predictions", "units": 2, "activation": "softmax"}}]}}
+    ckpt_dir = tmp_path / "ckpts" / spec.ckpt_name / "ckpt"
+    ckpt_dir.mkdir(parents=True)
+    np.savez(tmp_path / "p.npz", **{k: v.numpy() for k, v in params.items()})
+    (tmp_path / "c.json").write_text(json.dumps(cfg))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["/opt/conda/bin/python3.9", os.path.join(root, "tools", "npz_to_keras_h5.py"), str(tmp_path / "p.npz"),
+                        str(ckpt_dir / "0.h5"), str(tmp_path / "c.json")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    raws = [synth_jpeg(700 + i) for i in range(3)]
+    pix = [np.asarray(Image.open(io.BytesIO(b)).convert("RGB")) for b in raws]
+    x32 = torch.stack([R.decode_resize_normalize(p, hw, hw) for p in pix])
+    with torch.no_grad():
+        if key == "gcvit_tiny":
+            from oracle import gcvit_ref
+            z = gcvit_ref.forward_logits(params, x32, gcvit_ref.NAME2CONFIG[key], first_strides=1)
+        else:
+            from oracle import kecam_ref
+            f = kecam_ref.effnet_features(params, x32, "EfficientNetV2T", first_strides=1)
+            z = R.dense(R.global_avgpool(f), params["predictions/kernel"], params["predictions/bias"])
+    want = torch.softmax(z, -1).numpy()
+    for mode in ("fast", "strict"):
+        model = zoo.load_model(str(ckpt_dir / "0.h5"), precision=mode)
+        assert model.first_strides == 1 and model.head_act == "default"       # softmax on two classes IS the default pairing
+        x = pipeline.decode_jpegs(raws).resized(hw, hw, dtype=torch.float32 if mode == "strict" else torch.float16)
+        got = model.predict(x).float().cpu().numpy()
+        assert got.shape == (3, 2) and np.allclose(got.sum(1), 1.0, atol=1e-5)
+        d = np.abs(got - want).max()
+        score = ensemble.to_binary(got)[:, 0]                                  # main.py:113-114
+        report(f"[h5 variant] {key} first_strides=1, 2-class softmax, {mode}: max|dp| vs oracle {d:.2e}; scores {np.round(score, 4).tolist()}")
+        assert d <= (1e-4 if mode == "strict" else 5e-3) and np.allclose(score, 1.0 - want[:, 0], atol=(1e-4 if mode == "strict" else 5e-3))
+    # a weight-only file of the same variables cannot carry the variant: the default graph (first_strides 2) differs
+    r = subprocess.run(["/opt/conda/bin/python3.9", os.path.join(root, "tools", "npz_to_keras_h5.py"), str(tmp_path / "p.npz"),
+                        str(ckpt_dir / "1.h5")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m2 = zoo.load_model(str(ckpt_dir / "1.h5"))
+    assert m2.first_strides == 2

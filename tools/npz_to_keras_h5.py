@@ -1,6 +1,8 @@
 """Flat ``.npz`` of Keras-named arrays -> Keras-layout ``.h5`` weight file (root ``layer_names``, per-layer ``weight_names``, one
-dataset per variable; keras/saving/hdf5_format.py ``save_weights_to_hdf5_group``).  Needs h5py:
-    /opt/conda/bin/python3.9 tools/npz_to_keras_h5.py in.npz out.h5
+dataset per variable; keras/saving/hdf5_format.py ``save_weights_to_hdf5_group``), or with a third argument - a JSON file holding a
+Keras ``model_config`` - a FULL-MODEL file (``save_model_to_hdf5``: the same tree under ``model_weights`` plus the root attributes
+``model_config`` / ``keras_version`` / ``backend``).  Needs h5py:
+    /opt/conda/bin/python3.9 tools/npz_to_keras_h5.py in.npz out.h5 [model_config.json]
 Used by tests/test_h5lite_cpu.py to round-trip a whole member checkpoint through real libhdf5 output."""
 import sys
 import h5py
@@ -25,7 +27,13 @@ def put_attr(g, name, vals, limit=64512):
         g.attrs[f"{name}{i}"] = c
 
 
-with h5py.File(dst, "w") as f:
+with h5py.File(dst, "w") as top:
+    f = top
+    if len(sys.argv) > 3:
+        top.attrs["model_config"] = open(sys.argv[3]).read()          # str -> variable-length UTF-8, as Keras writes it
+        top.attrs["keras_version"] = "2.8.0"
+        top.attrs["backend"] = "tensorflow"
+        f = top.create_group("model_weights")
     put_attr(f, "layer_names", list(layers))
     f.attrs["backend"] = "tensorflow"
     f.attrs["keras_version"] = "2.8.0"

@@ -57,6 +57,7 @@ SIGNATURES = {
     "vip_mbconv_expand_dw_supported": (_i, [_i, _i, _i, _i]),
     "vip_mbconv_expand_dw_f16": (_i, [_vp] * 7 + [_i] * 14 + [_vp]),
     "vip_head_prob_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "vip_head_act_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vip_prob_to_score_f32": (_i, [_vp, _vp, _i, _i, _vp]),
     "vip_ensemble_mean_f32": (_i, [_vp, _vp, _i, _i, C.c_long, _vp]),
     "vip_gap_ln_dense_f32": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

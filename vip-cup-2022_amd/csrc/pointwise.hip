@@ -631,6 +631,36 @@ extern "C" int vip_head_prob_f32(const float* logits, float* prob, float* score,
     return vip_launch_status("vip_head_prob_f32");
 }
 
+namespace {
+// head activation other than the default pairing: act 0 = linear (logits out), 1 = elementwise sigmoid (any N), 2 = softmax (any N:
+// N = 1 gives 1.0, as Keras does)
+__global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__ z, float* __restrict__ p, int B, int N, int act) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* zb = z + (long)b * N;
+    float* pb = p + (long)b * N;
+    if (act == 0) {
+        for (int n = 0; n < N; ++n) pb[n] = zb[n];
+    } else if (act == 1) {
+        for (int n = 0; n < N; ++n) pb[n] = 1.f / (1.f + __expf(-zb[n]));
+    } else {
+        float m = zb[0];
+        for (int n = 1; n < N; ++n) m = fmaxf(m, zb[n]);
+        float sum = 0.f;
+        for (int n = 0; n < N; ++n) sum += __expf(zb[n] - m);
+        const float inv = 1.f / sum;
+        for (int n = 0; n < N; ++n) pb[n] = __expf(zb[n] - m) * inv;
+    }
+}
+}  // namespace
+
+extern "C" int vip_head_act_f32(const float* logits, float* prob, int B, int N, int act, void* stream) {
+    VIP_REQUIRE(logits && prob, VIP_ERR_BAD_ARG, "vip_head_act_f32: null pointer");
+    VIP_REQUIRE(B > 0 && N > 0 && act >= 0 && act <= 2, VIP_ERR_BAD_ARG, "vip_head_act_f32: bad dimension or activation code");
+    hipLaunchKernelGGL(head_act_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, prob, B, N, act);
+    return vip_launch_status("vip_head_act_f32");
+}
+
 extern "C" int vip_prob_to_score_f32(const float* prob, float* score, int B, int N, void* stream) {
     VIP_REQUIRE(prob && score, VIP_ERR_BAD_ARG, "vip_prob_to_score_f32: null pointer");
     VIP_REQUIRE(B > 0 && N > 0, VIP_ERR_BAD_ARG, "vip_prob_to_score_f32: non-positive dimension");

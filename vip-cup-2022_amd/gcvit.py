@@ -145,8 +145,10 @@ class _Block:
 @keras_predict
 class GCViT:
     def __init__(self, params: Dict[str, torch.Tensor], window_size, dim, depths, num_heads, mlp_ratio=3.0,
-                 layer_scale=None, classes: int = 1, device="cuda"):
+                 layer_scale=None, classes: int = 1, device="cuda", first_strides: int = 2, head_act: str = "default"):
         p, dev = params, device
+        self.first_strides = first_strides       # stride of the stem's conv_down reduction (embedding.py:8-16, feature.py:98; models/gcvit.py:47)
+        self.head_act = head_act                 # models/gcvit.py:48,113
         self.cfg = dict(window_size=window_size, dim=dim, depths=depths, num_heads=num_heads, mlp_ratio=mlp_ratio)
         self.classes = classes
         self.stem = ops.make_conv_weight(p["patch_embed/proj/kernel"], p["patch_embed/proj/bias"], device=dev,
@@ -195,7 +197,7 @@ class GCViT:
         """x: fp16 NHWC, RGB padded to 8 channels.  GCViT.forward_features (models/gcvit.py:98-105)."""
         assert x.shape[-1] == 8
         y = ops.conv2d(x, self.stem, stride=2, pad=PAD1)
-        y = self.stem_down(y)
+        y = self.stem_down(y, stride=self.first_strides)
         if collect is not None:
             collect.append(y)
         for lv in self.levels:
@@ -209,9 +211,9 @@ class GCViT:
 
     def predict(self, x):
         z = self.logits(x)
-        return ops.head_prob(z)
+        return ops.head_prob(z, getattr(self, "head_act", "default"))
 
 
-def GCViTTiny(params, classes=1, device="cuda"):
+def GCViTTiny(params, classes=1, device="cuda", first_strides=2, head_act="default"):
     """models/gcvit.py:151-160"""
-    return GCViT(params, **NAME2CONFIG["gcvit_tiny"], classes=classes, device=device)
+    return GCViT(params, **NAME2CONFIG["gcvit_tiny"], classes=classes, device=device, first_strides=first_strides, head_act=head_act)

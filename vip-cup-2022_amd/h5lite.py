@@ -535,3 +535,27 @@ def _load_keras_weights(path: str) -> Dict[str, np.ndarray]:
         for wn in chunked_attr(g, "weight_names") or []:
             out[wn.rsplit(":", 1)[0]] = g[wn].read()
     return out
+
+
+def load_keras_model_config(path: str) -> Optional[dict]:
+    """The ``model_config`` root attribute of a Keras full-model ``.h5`` (``model.save('x.h5')``: keras/saving/hdf5_format.py
+    ``save_model_to_hdf5`` writes ``json.dumps({'class_name': ..., 'config': ...})``) as a dictionary, or None for a weight-only file
+    (``model.save_weights``).  This is what ``tf.keras.models.load_model`` (main.py:107) rebuilds the graph from."""
+    import json
+    try:
+        f = File(path)
+        raw = f.attrs.get("model_config")
+        if raw is None:
+            return None
+        if isinstance(raw, np.ndarray):
+            raw = raw.item() if raw.ndim == 0 else raw.tolist()[0]
+        if isinstance(raw, (bytes, np.bytes_)):
+            raw = bytes(raw).decode("utf-8")
+        cfg = json.loads(raw)
+        if not isinstance(cfg, dict):
+            raise H5Error(f"{path}: model_config is not a JSON object")
+        return cfg
+    except H5Error:
+        raise
+    except (IndexError, KeyError, ValueError, OverflowError, MemoryError, RecursionError, UnicodeDecodeError, zlib.error, struct.error) as e:
+        raise H5Error(f"{path}: damaged HDF5 file ({type(e).__name__}: {e})") from e

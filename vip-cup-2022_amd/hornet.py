@@ -68,9 +68,10 @@ class _LN:
 @keras_predict
 class HorNet:
     def __init__(self, params: Dict[str, torch.Tensor], num_blocks, embed_dim, mlp_ratio=4, gn_split=(2, 3, 4, 5),
-                 scale=0.3333333, classes: int = 1, first_strides: int = 2, device="cuda"):
+                 scale=0.3333333, classes: int = 1, first_strides: int = 2, device="cuda", classifier_activation: str = "default"):
         p, dev = params, device
         self.classes, self.first_strides = classes, first_strides
+        self.head_act = classifier_activation
         self.stem = ops.make_conv_weight(p["stem_conv/kernel"], p["stem_conv/bias"], device=dev, pad_cin_to=8)
         self.stem_ln = _LN(p, "stem_ln", dev)
         self.stages = []
@@ -141,4 +142,4 @@ class HorNet:
 
     def predict(self, x):
         z = self.logits(x)
-        return ops.head_prob(z)
+        return ops.head_prob(z, getattr(self, "head_act", "default"))

@@ -65,7 +65,7 @@ class _Base:
 
     def predict(self, x):
         z = self.logits(x)
-        return ops.head_prob(z)
+        return ops.head_prob(z, getattr(self, "head_act", "default"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -114,8 +114,9 @@ def resnest_synth_params(seed: int, classes: int = 1, cfg=RESNEST50) -> Dict[str
 
 
 class ResNest(_Base):
-    def __init__(self, params, cfg=RESNEST50, classes=1, eps=1e-5, first_strides=2, device="cuda"):
+    def __init__(self, params, cfg=RESNEST50, classes=1, eps=1e-5, first_strides=2, device="cuda", classifier_activation="default"):
         p, dev = params, device
+        self.head_act = classifier_activation
         self.cfg, self.classes, self.first_strides = cfg, classes, first_strides
         self.stem = [_cbn(p, "stem_1_", "stem_1_", eps, dev, pad_cin=8), _cbn(p, "stem_2_", "stem_2_", eps, dev),
                      _cbn(p, "stem_3_", "stem_", eps, dev)]
@@ -262,8 +263,9 @@ def effnet_synth_params(name: str, seed: int, classes: int = 1) -> Dict[str, tor
 
 
 class EfficientNet(_Base):
-    def __init__(self, params, name: str, classes=1, first_strides=2, device="cuda"):
+    def __init__(self, params, name: str, classes=1, first_strides=2, device="cuda", classifier_activation="default"):
         p, dev = params, device
+        self.head_act = classifier_activation
         c = EFFNET[name]
         self.c, self.classes, self.first_strides = c, classes, first_strides
         self.torch_mode = c["is_torch_mode"]
@@ -386,8 +388,9 @@ def _std_fold(p, name, scale=1.0, gamma=SWISH_GAMMA, eps=1e-5):
 
 
 class NormFreeNet(_Base):
-    def __init__(self, params, cfg=NFNET_L0, classes=1, first_strides=2, device="cuda"):
+    def __init__(self, params, cfg=NFNET_L0, classes=1, first_strides=2, device="cuda", classifier_activation="default"):
         p, dev = params, device
+        self.head_act = classifier_activation
         self.cfg, self.classes, self.first_strides = cfg, classes, first_strides
         mk = lambda name, groups=1, in_scale=1.0, out_scale=1.0, pad_cin=None: ops.make_conv_weight(  # noqa: E731
             _std_fold(p, name, in_scale * out_scale)[0], _std_fold(p, name)[1] * out_scale, groups=groups, device=dev,

@@ -120,7 +120,9 @@ def main(argv=None):
             members.append((spec, None))
             continue
         if ckpts:
-            folds = [zoo.construct(spec, zoo.match_variable_names(spec, zoo.read_checkpoint(c)), **build) for c in ckpts]
+            # graph family from the directory name, variant (first_strides / classes / head activation) from the file's model_config
+            folds = [zoo.construct(spec, zoo.match_variable_names(spec, zoo.read_checkpoint(c)), variant=zoo.checkpoint_variant(spec, c),
+                                   **build) for c in ckpts]
         elif a.synthetic:
             folds = [zoo.build_member(key, **build)[1]]
         else:

@@ -691,12 +691,24 @@ def gap_ln_dense_f32(x, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w_n
     return out
 
 
-def head_prob(z: torch.Tensor) -> torch.Tensor:
-    """fp32 logits ``[B, N]`` -> what ``model.predict`` returns: sigmoid for one class, softmax otherwise (fp32 ``[B, N]``)."""
+HEAD_ACTS = {"linear": 0, None: 0, "none": 0, "sigmoid": 1, "softmax": 2}
+
+
+def head_prob(z: torch.Tensor, act="default") -> torch.Tensor:
+    """fp32 logits ``[B, N]`` -> what ``model.predict`` returns (fp32 ``[B, N]``).  ``act="default"``: sigmoid for one class, softmax
+    otherwise - the pairing of every constructor default; otherwise the classifier activation the checkpoint's model_config names
+    (``"sigmoid"`` / ``"softmax"`` / ``"linear"``: resnet_rs_model.py:474-476 ``classifier_activation``, gcvit models/gcvit.py:113 ``head_act``)."""
     assert z.dtype == torch.float32 and z.is_cuda and z.dim() == 2 and z.is_contiguous()
     out = torch.empty_like(z)
-    st = _abi.lib().vip_head_prob_f32(_p(z), _p(out), None, z.shape[0], z.shape[1], _stream())
-    _abi.check(st, "vip_head_prob_f32")
+    n = z.shape[1]
+    if act == "default" or (act == "sigmoid" and n == 1) or (act == "softmax" and n > 1):
+        st = _abi.lib().vip_head_prob_f32(_p(z), _p(out), None, z.shape[0], n, _stream())
+        _abi.check(st, "vip_head_prob_f32")
+        return out
+    if act not in HEAD_ACTS:
+        raise ValueError(f"head activation {act!r}: expected one of {sorted(k for k in HEAD_ACTS if isinstance(k, str))}")
+    st = _abi.lib().vip_head_act_f32(_p(z), _p(out), z.shape[0], n, HEAD_ACTS[act], _stream())
+    _abi.check(st, "vip_head_act_f32")
     return out
 
 

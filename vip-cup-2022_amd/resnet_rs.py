@@ -71,8 +71,9 @@ class ResNetRS:
 
     def __init__(self, params: Dict[str, torch.Tensor], depth: int = 50, bn_epsilon: float = 1e-5,
                  activation: str = "relu", se_ratio: float = 0.25, classes: int = 1, first_strides: int = 2,
-                 block_args: List = None, device="cuda"):
+                 block_args: List = None, device="cuda", classifier_activation: str = "default"):
         self.act = activation
+        self.head_act = classifier_activation          # resnet_rs_model.py:337,474-476
         self.first_strides = first_strides
         self.classes = classes
         self.device = device
@@ -151,9 +152,10 @@ class ResNetRS:
     def predict(self, x: torch.Tensor) -> torch.Tensor:
         """``model.predict`` equivalent (main.py:109): sigmoid for 1 class, softmax otherwise (host, B x classes floats)."""
         z = self.logits(x)
-        return ops.head_prob(z)
+        return ops.head_prob(z, getattr(self, "head_act", "default"))
 
 
-def ResNetRS50(params, classes=1, first_strides=2, device="cuda"):
+def ResNetRS50(params, classes=1, first_strides=2, device="cuda", classifier_activation="default"):
     """resnet_rs_model.py:516-540"""
-    return ResNetRS(params, depth=50, classes=classes, first_strides=first_strides, device=device)
+    return ResNetRS(params, depth=50, classes=classes, first_strides=first_strides, device=device,
+                    classifier_activation=classifier_activation)

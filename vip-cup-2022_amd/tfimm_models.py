@@ -51,6 +51,19 @@ class ViTConfig:
         return self.grid_size[0] * self.grid_size[1]
 
 
+def variant(cfg, overrides: Dict):
+    """config dataclass with the fields a checkpoint's model_config overrides (tfimm serialises the dataclass itself,
+    models/serialization.py:75-76); unknown keys are an error, fields this graph does not read are ignored by the caller"""
+    import dataclasses
+    if not overrides:
+        return cfg
+    known = {f.name for f in dataclasses.fields(cfg)}
+    bad = set(overrides) - known
+    if bad:
+        raise ValueError(f"{cfg.name}: unknown config fields {sorted(bad)}")
+    return dataclasses.replace(cfg, **overrides)
+
+
 VIT_CONFIGS = {
     "vit_tiny_patch16_224": ViTConfig("vit_tiny_patch16_224", embed_dim=192, nb_heads=3),    # vit.py:470-481
     "vit_small_patch16_224": ViTConfig("vit_small_patch16_224", embed_dim=384, nb_heads=6),  # vit.py:530-541
@@ -127,7 +140,7 @@ class ViT:
 
     def predict(self, x):
         z = self.logits(x)
-        return ops.head_prob(z)
+        return ops.head_prob(z, getattr(self, "head_act", "default"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -233,4 +246,4 @@ class ConvNeXt:
 
     def predict(self, x):
         z = self.logits(x)
-        return ops.head_prob(z)
+        return ops.head_prob(z, getattr(self, "head_act", "default"))

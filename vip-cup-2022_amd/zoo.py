@@ -6,7 +6,7 @@ seeded synthetic checkpoint (synth.py); ``params`` dictionaries use the referenc
 """
 import os
 from dataclasses import dataclass
-from typing import Callable, Dict, List, Tuple
+from typing import Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -25,76 +25,77 @@ class MemberSpec:
     oracle: str          # module under oracle/ that restates the graph (used by tests / bench cpu leg only)
     gmac_per_image: float  # algorithmic GMAC / image
     head: str = "predictions"  # Keras name of the classifier Dense
+    family: str = ""           # constructor-argument dialect for checkpoint variants (variant_kwargs): filled in below from `oracle`
 
 
 MEMBERS: Dict[str, MemberSpec] = {
     "resnet_rs50": MemberSpec("resnet_rs50", "ResNetRS50-200x200", 200, 1006,
                               lambda seed: resnet_rs.synth_params(50, seed),
-                              lambda p: resnet_rs.ResNetRS50(p), "resnet_rs_ref", 3.790),
+                              lambda p, **kw: resnet_rs.ResNetRS50(p, **kw), "resnet_rs_ref", 3.790),
     # members of the earlier, larger ensembles that are plain re-configurations of graphs built here (main.py:43-56)
     "resnet_rs101": MemberSpec("resnet_rs101", "ResNetRS101-200x200", 200, 1016, lambda seed: resnet_rs.synth_params(101, seed),
-                               lambda p: resnet_rs.ResNetRS(p, depth=101), "resnet_rs_ref", 7.30),
+                               lambda p, **kw: resnet_rs.ResNetRS(p, depth=101, **kw), "resnet_rs_ref", 7.30),
     "resnet_rs200": MemberSpec("resnet_rs200", "ResNetRS200-200x200", 200, 1026, lambda seed: resnet_rs.synth_params(200, seed),
-                               lambda p: resnet_rs.ResNetRS(p, depth=200), "resnet_rs_ref", 14.7),
+                               lambda p, **kw: resnet_rs.ResNetRS(p, depth=200, **kw), "resnet_rs_ref", 14.7),
     "convnext_small_in22k": MemberSpec("convnext_small_in22k", "convnext_small_in22k-200x200", 200, 1010,
                                        lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_small_in22k"], seed),
-                                       lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_small_in22k"]), "tfimm_ref", 25.9, "head/fc"),
+                                       lambda p, **kw: tm.ConvNeXt(p, tm.variant(tm.CONVNEXT_CONFIGS["convnext_small_in22k"], kw)), "tfimm_ref", 25.9, "head/fc"),
     "convnext_base_in22k": MemberSpec("convnext_base_in22k", "convnext_base_in22k-200x200", 200, 1020,
                                       lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_base_in22k"], seed),
-                                      lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_base_in22k"]), "tfimm_ref", 45.8, "head/fc"),
+                                      lambda p, **kw: tm.ConvNeXt(p, tm.variant(tm.CONVNEXT_CONFIGS["convnext_base_in22k"], kw)), "tfimm_ref", 45.8, "head/fc"),
     "convnext_large_in22ft1k": MemberSpec("convnext_large_in22ft1k", "convnext_large_in22ft1k-200x200", 200, 1030,
                                           lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"], seed),
-                                          lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"]), "tfimm_ref", 102.7, "head/fc"),
+                                          lambda p, **kw: tm.ConvNeXt(p, tm.variant(tm.CONVNEXT_CONFIGS["convnext_large_in22ft1k"], kw)), "tfimm_ref", 102.7, "head/fc"),
     "resnest200": MemberSpec("resnest200", "ResNest200-200x200", 200, 1021, lambda seed: km.resnest_synth_params(seed, cfg=km.RESNEST200),
-                             lambda p: km.ResNest(p, cfg=km.RESNEST200), "kecam_ref", 29.0),
+                             lambda p, **kw: km.ResNest(p, cfg=km.RESNEST200, **kw), "kecam_ref", 29.0),
     "resnet200d": MemberSpec("resnet200d", "ResNet200D-200x200", 200, 1027, lambda seed: km.resnest_synth_params(seed, cfg=km.RESNET200D),
-                             lambda p: km.ResNest(p, cfg=km.RESNET200D), "kecam_ref", 12.0),
+                             lambda p, **kw: km.ResNest(p, cfg=km.RESNET200D, **kw), "kecam_ref", 12.0),
     "eca_nfnet_l2": MemberSpec("eca_nfnet_l2", "ECA_NFNetL2-200x200", 200, 1025, lambda seed: km.nfnet_synth_params(seed, cfg=km.NFNET_L2),
-                               lambda p: km.NormFreeNet(p, cfg=km.NFNET_L2), "kecam_ref", 10.6),
+                               lambda p, **kw: km.NormFreeNet(p, cfg=km.NFNET_L2, **kw), "kecam_ref", 10.6),
     "efficientnet_v2m": MemberSpec("efficientnet_v2m", "EfficientNetV2M-200x200", 200, 1023,
                                    lambda seed: km.effnet_synth_params("EfficientNetV2M", seed),
-                                   lambda p: km.EfficientNet(p, "EfficientNetV2M"), "kecam_ref", 4.3),
+                                   lambda p, **kw: km.EfficientNet(p, "EfficientNetV2M", **kw), "kecam_ref", 4.3),
     "efficientnet_v2l": MemberSpec("efficientnet_v2l", "EfficientNetV2L-200x200", 200, 1024,
                                    lambda seed: km.effnet_synth_params("EfficientNetV2L", seed),
-                                   lambda p: km.EfficientNet(p, "EfficientNetV2L"), "kecam_ref", 9.8),
+                                   lambda p, **kw: km.EfficientNet(p, "EfficientNetV2L", **kw), "kecam_ref", 9.8),
     "convnext_base_384_in22ft1k": MemberSpec("convnext_base_384_in22ft1k", "convnext_base_384_in22ft1k-200x200", 200, 1031,
         lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_base_384_in22ft1k"], seed),
-        lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_base_384_in22ft1k"]), "tfimm_ref", 45.8, "head/fc"),
+        lambda p, **kw: tm.ConvNeXt(p, tm.variant(tm.CONVNEXT_CONFIGS["convnext_base_384_in22ft1k"], kw)), "tfimm_ref", 45.8, "head/fc"),
     "convnext_large_384_in22ft1k": MemberSpec("convnext_large_384_in22ft1k", "convnext_large_384_in22ft1k-200x200", 200, 1033,
         lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_large_384_in22ft1k"], seed),
-        lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_large_384_in22ft1k"]), "tfimm_ref", 102.7, "head/fc"),
+        lambda p, **kw: tm.ConvNeXt(p, tm.variant(tm.CONVNEXT_CONFIGS["convnext_large_384_in22ft1k"], kw)), "tfimm_ref", 102.7, "head/fc"),
     "hornet_base": MemberSpec("hornet_base", "HorNetBase-200x200", 200, 1028,
                               lambda seed: hornet.synth_params(hornet.CONFIGS["hornet_base"], seed),
-                              lambda p: hornet.HorNet(p, **hornet.CONFIGS["hornet_base"]), "hornet_ref", 11.6),
+                              lambda p, **kw: hornet.HorNet(p, **hornet.CONFIGS["hornet_base"], **kw), "hornet_ref", 11.6),
     "gcvit_base": MemberSpec("gcvit_base", "GCViTBase-224x224", 224, 1022,
                              lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_base"], seed),
-                             lambda p: gcvit.GCViT(p, **gcvit.NAME2CONFIG["gcvit_base"]), "gcvit_ref", 14.3, "head"),
+                             lambda p, **kw: gcvit.GCViT(p, **gcvit.NAME2CONFIG["gcvit_base"], **kw), "gcvit_ref", 14.3, "head"),
     "gcvit_tiny": MemberSpec("gcvit_tiny", "GCViTTiny-224x224", 224, 1002,
                              lambda seed: gcvit.synth_params(gcvit.NAME2CONFIG["gcvit_tiny"], seed),
-                             lambda p: gcvit.GCViTTiny(p), "gcvit_ref", 4.760, "head"),
+                             lambda p, **kw: gcvit.GCViTTiny(p, **kw), "gcvit_ref", 4.760, "head"),
     "convnext_tiny_in22k": MemberSpec("convnext_tiny_in22k", "convnext_tiny_in22k-200x200", 200, 1000,
                                       lambda seed: tm.convnext_synth_params(tm.CONVNEXT_CONFIGS["convnext_tiny_in22k"], seed),
-                                      lambda p: tm.ConvNeXt(p, tm.CONVNEXT_CONFIGS["convnext_tiny_in22k"]),
+                                      lambda p, **kw: tm.ConvNeXt(p, tm.variant(tm.CONVNEXT_CONFIGS["convnext_tiny_in22k"], kw)),
                                       "tfimm_ref", 13.33, "head/fc"),
     "resnest50": MemberSpec("resnest50", "ResNest50-200x200", 200, 1001, lambda seed: km.resnest_synth_params(seed),
-                            lambda p: km.ResNest(p), "kecam_ref", 4.518),
+                            lambda p, **kw: km.ResNest(p, **kw), "kecam_ref", 4.518),
     "efficientnet_v2t": MemberSpec("efficientnet_v2t", "EfficientNetV2T-200x200", 200, 1003,
                                    lambda seed: km.effnet_synth_params("EfficientNetV2T", seed),
-                                   lambda p: km.EfficientNet(p, "EfficientNetV2T"), "kecam_ref", 1.627),
+                                   lambda p, **kw: km.EfficientNet(p, "EfficientNetV2T", **kw), "kecam_ref", 1.627),
     "efficientnet_v1b4": MemberSpec("efficientnet_v1b4", "EfficientNetV1B4-224x224", 224, 1004,
                                     lambda seed: km.effnet_synth_params("EfficientNetV1B4", seed),
-                                    lambda p: km.EfficientNet(p, "EfficientNetV1B4"), "kecam_ref", 1.502),
+                                    lambda p, **kw: km.EfficientNet(p, "EfficientNetV1B4", **kw), "kecam_ref", 1.502),
     "eca_nfnet_l0": MemberSpec("eca_nfnet_l0", "ECA_NFNetL0-200x200", 200, 1005, lambda seed: km.nfnet_synth_params(seed),
-                               lambda p: km.NormFreeNet(p), "kecam_ref", 3.617),
+                               lambda p, **kw: km.NormFreeNet(p, **kw), "kecam_ref", 3.617),
     "vit_tiny_patch16_224": MemberSpec("vit_tiny_patch16_224", "vit_tiny_patch16_224-224x224", 224, 1008,
                                        lambda seed: tm.vit_synth_params(tm.VIT_CONFIGS["vit_tiny_patch16_224"], seed),
-                                       lambda p: tm.ViT(p, tm.VIT_CONFIGS["vit_tiny_patch16_224"]), "tfimm_ref", 1.253, "head"),
+                                       lambda p, **kw: tm.ViT(p, tm.variant(tm.VIT_CONFIGS["vit_tiny_patch16_224"], kw)), "tfimm_ref", 1.253, "head"),
     "vit_small_patch16_224": MemberSpec("vit_small_patch16_224", "vit_small_patch16_224-224x224", 224, 1007,
                                         lambda seed: tm.vit_synth_params(tm.VIT_CONFIGS["vit_small_patch16_224"], seed),
-                                        lambda p: tm.ViT(p, tm.VIT_CONFIGS["vit_small_patch16_224"]), "tfimm_ref", 4.598, "head"),
+                                        lambda p, **kw: tm.ViT(p, tm.variant(tm.VIT_CONFIGS["vit_small_patch16_224"], kw)), "tfimm_ref", 4.598, "head"),
     "vit_base_patch16_224": MemberSpec("vit_base_patch16_224", "vit_base_patch16_224-224x224", 224, 1009,
                                        lambda seed: tm.vit_synth_params(tm.VIT_CONFIGS["vit_base_patch16_224"], seed),
-                                       lambda p: tm.ViT(p, tm.VIT_CONFIGS["vit_base_patch16_224"]), "tfimm_ref", 17.56, "head"),
+                                       lambda p, **kw: tm.ViT(p, tm.variant(tm.VIT_CONFIGS["vit_base_patch16_224"], kw)), "tfimm_ref", 17.56, "head"),
 }
 
 # order of ckpts/ckpts.json:2-8 (members are appended here as their graphs land)
@@ -125,7 +126,8 @@ def build_params(name: str, calibrated: bool = True):
     return params
 
 
-def construct(spec: MemberSpec, params, bias_calibration: bool = True, precision: str = None, calibration_batch=None):
+def construct(spec: MemberSpec, params, bias_calibration: bool = True, precision: str = None, calibration_batch=None,
+              variant: Optional[dict] = None):
     """``spec.ctor(params)`` in a precision mode (``ops.PRECISION`` when None; env ``VIP_PRECISION``):
 
     * ``"fast"``: fp16 weights, followed on a GPU by one calibration pass (ops.calibration: the image-independent part of the fp16
@@ -134,24 +136,27 @@ def construct(spec: MemberSpec, params, bias_calibration: bool = True, precision
       needs typical per-channel input means).  ``bias_calibration=False`` (or env ``VIP_BIAS_CALIBRATION=0``) gives the plain fp16 model.
     * ``"strict"``: fp32 weights exactly as in the checkpoint, nothing to calibrate; the model takes fp32 inputs.
 
+    ``variant``: constructor arguments that differ from the member's defaults (``variant_kwargs``: what a checkpoint's model_config says
+    about first_strides / classes / head activation).
     The mode is recorded as ``model.precision``; ``ensemble.member_input`` feeds each member the input dtype it was built for."""
     from . import ops, pipeline
     mode = precision or ops.PRECISION
+    ctor = (lambda p: spec.ctor(p, **variant)) if variant else spec.ctor
     if mode == "strict":
         with ops.precision("strict"):
-            model = spec.ctor(params)
+            model = ctor(params)
         model.precision = "strict"
         return model
     with ops.precision("fast"):
         if os.environ.get("VIP_BIAS_CALIBRATION", "1") == "0":     # profiling runs: keep the calibration launches out of the trace
             bias_calibration = False
         if not (bias_calibration and torch.cuda.is_available()):
-            model = spec.ctor(params)
+            model = ctor(params)
             model.precision = "fast"
             return model
         ops.KEEP_ROUNDING_ERROR = True
         try:
-            model = spec.ctor(params)
+            model = ctor(params)
         finally:
             ops.KEEP_ROUNDING_ERROR = False
         model.precision = "fast"
@@ -261,4 +266,106 @@ def load_model(path: str, compile: bool = False, precision: str = None, bias_cal
     if key is None:
         raise ValueError(f"load_model: no graph for checkpoint directory {model_name!r}")
     spec = MEMBERS[key]
-    return construct(spec, match_variable_names(spec, read_checkpoint(path)), bias_calibration, precision, calibration_batch)
+    variant = checkpoint_variant(spec, path)
+    return construct(spec, match_variable_names(spec, read_checkpoint(path)), bias_calibration, precision, calibration_batch, variant)
+
+
+# ---- graph variants from a checkpoint's model_config ---------------------------------------------------------------------------
+# tf.keras.models.load_model (main.py:107) rebuilds the graph from the file's `model_config`, so whatever non-default constructor
+# arguments the lost checkpoints were trained with (first_strides, number of classes, head activation) come with the
+# file.  Here the member FAMILY is picked from the directory name (as the reference picks its batch size, main.py:70-71,85) and the
+# variant arguments are read from model_config; a weight-only file (model.save_weights) has none and gets the constructor defaults.
+def _walk_layers(cfg):
+    """every {"class_name", "config"} node of a Keras model_config in serialisation order, nested models included"""
+    if not isinstance(cfg, dict):
+        return
+    yield cfg
+    inner = cfg.get("config")
+    if isinstance(inner, dict):
+        for layer in inner.get("layers", []) or []:
+            yield from _walk_layers(layer)
+    elif isinstance(inner, list):                      # old Sequential form: config IS the layer list
+        for layer in inner:
+            yield from _walk_layers(layer)
+
+
+def variant_from_model_config(cfg: Optional[dict]) -> dict:
+    """What a Keras ``model_config`` says about the arguments the member constructors expose:
+    ``input_hw`` (InputLayer batch_input_shape), ``first_strides`` (a custom layer's own ``first_strides`` entry - gcvit ``Stem``,
+    layers/embedding.py:25-29 - else the strides of the first Conv2D: the stem conv of resnet_rs_model.py:97-104 and of the kecam
+    graphs), ``classes`` and ``head_act`` (units / activation of the LAST Dense: resnet_rs_model.py:474-476, common_layers.py:278-283),
+    and for a tfimm model (class ``...>ViT`` / ``...>ConvNeXt`` serialised by tfimm/models/serialization.py:21-89 as its config
+    dataclass) the dataclass fields themselves under ``tfimm_cfg``.  Keys that the file does not determine are absent."""
+    out: dict = {}
+    if not cfg:
+        return out
+    first_conv, last_dense = None, None
+    for node in _walk_layers(cfg):
+        cname = str(node.get("class_name", ""))
+        c = node.get("config") if isinstance(node.get("config"), dict) else {}
+        short = cname.split(">")[-1]
+        if short == "InputLayer" and "input_hw" not in out:
+            shp = c.get("batch_input_shape") or c.get("batch_shape")
+            if shp and len(shp) == 4 and shp[1] and shp[2]:
+                out["input_hw"] = (int(shp[1]), int(shp[2]))
+        if "first_strides" in c and "first_strides" not in out:
+            out["first_strides"] = int(c["first_strides"])
+        if short == "Conv2D" and first_conv is None:
+            first_conv = c
+        if short == "Dense":
+            last_dense = c
+        if short in ("ViT", "ConvNeXt") and "nb_classes" in c:
+            out["tfimm_cfg"] = dict(c)
+            out["classes"] = int(c["nb_classes"])
+            if c.get("input_size"):
+                out["input_hw"] = (int(c["input_size"][0]), int(c["input_size"][1]))
+        if short == "GCViT":
+            for k_src, k_dst in (("num_classes", "classes"), ("head_act", "head_act"), ("first_strides", "first_strides")):
+                if k_src in c:
+                    out[k_dst] = c[k_src]
+    if "first_strides" not in out and first_conv is not None and first_conv.get("strides"):
+        st = first_conv["strides"]
+        out["first_strides"] = int(st[0] if isinstance(st, (list, tuple)) else st)
+    if last_dense is not None and "classes" not in out:
+        out["classes"] = int(last_dense["units"])
+        out["head_act"] = last_dense.get("activation") or "linear"
+    return out
+
+
+def variant_kwargs(spec: MemberSpec, info: dict) -> dict:
+    """``variant_from_model_config`` output -> keyword arguments of ``spec.ctor`` (only what differs from the defaults is passed)"""
+    kw: dict = {}
+    if not info:
+        return kw
+    hw = info.get("input_hw")
+    if hw is not None and tuple(hw) != (spec.input_hw, spec.input_hw):
+        raise ValueError(f"{spec.ckpt_name}: the checkpoint's model_config was built for {hw[0]}x{hw[1]} inputs, the manifest says "
+                         f"{spec.input_hw}x{spec.input_hw}")
+    fam = spec.oracle
+    classes, act, fs = info.get("classes"), info.get("head_act"), info.get("first_strides")
+    if fam == "tfimm_ref":                              # dataclass fields (tfimm_models.variant keeps the ones the graph uses)
+        c = info.get("tfimm_cfg") or {}
+        for k in ("nb_classes", "patch_size", "first_down"):
+            if k in c:
+                kw[k] = c[k]
+        if classes is not None and "nb_classes" not in kw:
+            kw["nb_classes"] = classes
+        return kw
+    if classes is not None and classes != 1:
+        kw["classes"] = int(classes)
+    if fs is not None and fs != 2:
+        kw["first_strides"] = int(fs)
+    default_act = "sigmoid" if (classes or 1) == 1 else "softmax"
+    if act is not None and act != default_act:
+        if act not in ("sigmoid", "softmax", "linear"):
+            raise ValueError(f"{spec.ckpt_name}: classifier activation {act!r} in model_config is not supported")
+        kw["head_act" if fam == "gcvit_ref" else "classifier_activation"] = act
+    return kw
+
+
+def checkpoint_variant(spec: MemberSpec, path: str) -> dict:
+    """constructor keyword arguments a checkpoint file asks for ({} for weight-only files and .npz)"""
+    if not path.endswith((".h5", ".hdf5")):
+        return {}
+    from . import h5lite
+    return variant_kwargs(spec, variant_from_model_config(h5lite.load_keras_model_config(path)))
