@@ -15,8 +15,8 @@
 //     one LDS read with an immediate offset per score, no index arithmetic; padded key slots are
 //     redirected to a block of -1e30 by swapping the base register.
 //
-// Math, per 16-query tile: S^T = K Q^T with v_mfma_f32_16x16x32_f16 (keys on rows, queries on the
-// lane: the whole head_dim is one MFMA), so the softmax over keys is register-local plus two cross-lane
+// Math, per 16-query tile: S^T = K Q^T + bias with v_mfma_f32_16x16x32_f16 (keys on rows, queries on the
+// lane: the whole head_dim is one MFMA, the table values are its C operand), so the softmax over keys is register-local plus two cross-lane
 // exchanges, the probabilities are already the B operand of O^T = V^T P^T, V^T fragments come from
 // ds_read_b64_tr_b16, and the 1/rowsum is lane-local.  Q fragments are loaded straight from global.
 //
@@ -25,6 +25,21 @@
 // (conflict-free transposed reads).
 #include "common.hpp"
 #include <stdlib.h>
+
+// CONCURRENCY NOTE (round 3, tools/stress_determinism.py -> bisect_determinism.py -> attn_race2.py).  Rounds 1-2 computed S^T with a
+// zero C operand, then read the relative-position table from LDS and added it with v_pk_add_f32.  That form is bit-exact when the
+// kernel has the chip to itself and WRONG when waves of another MFMA-heavy kernel share its SIMDs (the ensemble runs its members on
+// several streams): with a pure-MFMA co-runner 39 of 40 launches returned a few (window, head, 16-query tile) blocks with
+// deterministic wrong values (|d| up to 1.0), which is what made GCViT's scores differ between pipelined and joined bench steps.
+// What did NOT help: up to 128 wait states between the MFMAs and their consumers, every MFMA source operand in registers of its own
+// kept live to the end of the tile, s_setprio, 40 KB of extra LDS.  What does: the table values are read BEFORE the MFMAs, straight
+// into the accumulators, and go in as the MFMA's C operand - no LDS return lands and no packed add runs between the MFMAs and the
+// softmax (and the tile saves its 28 packed adds).  40 of 40 launches bit-identical under every co-runner, both window sizes.
+// WA_PV_OPERANDS_FIRST: the P.V MFMAs take all their operands (P^T fragments, V^T fragments) from registers that are complete before
+// the first of them issues (1), or convert / read them step by step between the MFMAs as rounds 1-2 did (0).
+#ifndef WA_PV_OPERANDS_FIRST
+#define WA_PV_OPERANDS_FIRST 1
+#endif
 
 namespace {
 
@@ -85,48 +100,43 @@ __device__ __forceinline__ void win_query_tile(const WinArgs& a, const U4H8& qfr
     {
         const int qn = qt * 16 + l15;
 
-        // S^T tiles: rows = keys 16t + 4g + r, column = this lane's query.  The relative-position bias (stored as
-        // table/scale, padded key slots redirected to the -1e30 block) is added with one packed add per pair (as the MFMA
-        // C operand it cost a v_mov per value to assemble), so the softmax needs one packed FMA + one exp2 per score:
-        //   p = exp2(scale*log2e * s' - scale*log2e * max s')
+        // the softmax needs one packed FMA + one exp2 per score:  p = exp2(scale*log2e * s' - scale*log2e * max s'),  s' = q.k + bias/scale
         const int qy = qn / WS, qx = qn - qy * WS;
         const int qyc = qy < WS ? qy : WS - 1, qxc = qx;
         const float* tbase = tb + (Cfg::TOFF + qyc * Cfg::TW + qxc + (WS - 1) * (Cfg::TW + 1) - lane_term - Cfg::KCMAX);
+        // S^T tiles: rows = keys 16t + 4g + r, column = this lane's query.  The accumulators START as the relative-position bias
+        // (stored as table / scale; padded key slots redirected to the -1e30 block): one LDS read with an immediate offset per score,
+        // issued and returned before the first MFMA, then C operand of S^T = K Q^T + bias.
         f32x4 acc[NKT];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // which lane groups g hold a padded key slot in register (t, r)?  (compile-time 4-bit mask)
+                int mask = 0;
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int kp = 16 * t + 4 * gg + r;
+                    if (((kp & (P - 1)) >= WS) || ((kp >> LOG2P) >= WS)) mask |= 1 << gg;
+                }
+                if (mask == 15) {
+                    acc[t][r] = -1.0e30f;
+                } else {
+                    const int imm = Cfg::KCMAX - (Cfg::KSTEP * t + r);
+                    const float* bp = (mask == 0) ? tbase : (((mask >> g) & 1) ? tb : tbase);
+                    acc[t][r] = bp[imm];
+                }
+            }
+        U4H8 kf[NKT];
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
             const int row = t * 16 + l15;
-            U4H8 kf;
-            kf.u = *reinterpret_cast<const uint4*>(k_lds + row * Cfg::ROWB + k_slot(row, g) * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf.h, qfrag.h, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            kf[t].u = *reinterpret_cast<const uint4*>(k_lds + row * Cfg::ROWB + k_slot(row, g) * 16);
         }
+        __builtin_amdgcn_sched_barrier(0);      // every LDS read above is issued before the first MFMA below
 #pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                f32x2 bv;
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    // which lane groups g hold a padded key slot in register (t, r+rr)?  (compile-time 4-bit mask)
-                    int mask = 0;
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const int kp = 16 * t + 4 * gg + r + rr;
-                        if (((kp & (P - 1)) >= WS) || ((kp >> LOG2P) >= WS)) mask |= 1 << gg;
-                    }
-                    if (mask == 15) {
-                        bv[rr] = -1.0e30f;
-                    } else {
-                        const int imm = Cfg::KCMAX - (Cfg::KSTEP * t + r + rr);
-                        const float* bp = (mask == 0) ? tbase : (((mask >> g) & 1) ? tb : tbase);
-                        bv[rr] = bp[imm];
-                    }
-                }
-                const f32x2 sv = (f32x2){acc[t][r], acc[t][r + 1]} + bv;   // v_pk_add_f32
-                acc[t][r] = sv.x;
-                acc[t][r + 1] = sv.y;
-            }
-        }
+        for (int t = 0; t < NKT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t].h, qfrag.h, acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         float m = -1.0e30f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -156,6 +166,36 @@ __device__ __forceinline__ void win_query_tile(const WinArgs& a, const U4H8& qfr
         // accumulators: MFMA k-slot (g, j) carries key 32s + 4g + j (j < 4) / 32s + 16 + 4g + (j-4).
         f32x4 o[2];
         o[0] = o[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if WA_PV_OPERANDS_FIRST
+        U4H8 pfa[NKT / 2];
+        union VF {
+            fp16x4_t t[2];
+            f16x8 v;
+        } vfa[NKT / 2][2];
+#pragma unroll
+        for (int s = 0; s < NKT / 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pfa[s].e[j] = (f16)acc[2 * s][j];
+                pfa[s].e[4 + j] = (f16)acc[2 * s + 1][j];
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int row = 32 * s + 16 * hh + 4 * g + tr_q;
+                    const int half = dt ^ ((row >> 2) & 1);  // = dt ^ (g & 1): 32-byte halves swapped on odd row quads
+                    vfa[s][dt].t[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                        (__attribute__((address_space(3))) fp16x4_t*)(v_lds + row * Cfg::ROWB + half * 32 + tr_p * 8));
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NKT / 2; ++s)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfa[s][dt].v, pfa[s].h, o[dt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
         for (int s = 0; s < NKT / 2; ++s) {
             U4H8 pf;
@@ -180,6 +220,7 @@ __device__ __forceinline__ void win_query_tile(const WinArgs& a, const U4H8& qfr
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf.v, pf.h, o[dt], 0, 0, 0);
             }
         }
+#endif
 
         // store: lane owns query qn, head-dim d = 16*dt + 4g + (0..3).  Lane pairs (g, g^1) swap one 8-byte half so
         // that every lane holds 8 CONSECUTIVE channels and the four lanes of a token write its whole 64-byte head
