@@ -1,0 +1,97 @@
+"""Results must not depend on what else the chip is running.  Round 2's window-attention kernel was bit-exact alone and wrong (|d| up to
+1.0 on a few 16-query blocks, deterministic values) whenever waves of another MFMA-heavy kernel shared its SIMDs - which is what the
+ensemble's three member streams do all the time, and what made pipelined and joined bench steps differ (DESIGN.md section 8.6 of round 2;
+found with tools/stress_determinism.py -> tools/bisect_determinism.py -> tools/race_matrix.py).  Every MFMA kernel family of the
+library is launched here on one stream while a second stream keeps the matrix pipes busy, and compared BIT FOR BIT with its solo result."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tools.make_synth import synth_jpeg  # noqa: E402
+
+
+def _victims():
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ops
+    g = torch.Generator().manual_seed(3)
+
+    def r(*shape):
+        return torch.randn(*shape, generator=g).to(torch.float16).cuda()
+
+    qkv14, tab14 = r(64, 14, 14, 768), (torch.randn(27 * 27, 8, generator=g) * 0.5).cuda()
+    qkv14g, qg14 = r(64, 14, 14, 512), r(64, 196, 256)
+    qkv7, tab7 = r(16, 56, 56, 192), (torch.randn(13 * 13, 2, generator=g) * 0.5).cuda()
+    qkvm = r(32, 197, 3 * 384)
+    xm = r(64 * 56 * 56, 96)
+    f1 = ops.make_dense_weight(torch.randn(96, 384, generator=g) / 10, torch.zeros(384))
+    f2 = ops.make_dense_weight(torch.randn(384, 96, generator=g) / 20, torch.zeros(96))
+    xg = r(50176, 256)
+    cw = ops.make_dense_weight(torch.randn(256, 768, generator=g) / 16, torch.zeros(768))
+    xc3 = r(64, 50, 50, 64)
+    cw3 = ops.make_conv_weight(torch.randn(3, 3, 64, 64, generator=g) / 24, torch.zeros(64))
+    with ops.precision("strict"):
+        cws = ops.make_conv_weight(torch.randn(1, 1, 256, 256, generator=g) / 16, torch.zeros(256))
+    xs32 = torch.randn(64, 14, 14, 256, generator=g).cuda()
+    return {
+        "window_attn ws14": lambda: ops.window_attention(qkv14, None, tab14, 8, 14, 32 ** -0.5),
+        "window_attn ws14 global": lambda: ops.window_attention(qkv14g, qg14, tab14, 8, 14, 32 ** -0.5),
+        "window_attn ws7": lambda: ops.window_attention(qkv7, None, tab7, 2, 7, 32 ** -0.5),
+        "mhsa": lambda: ops.mhsa(qkvm, 6, 0.125),
+        "mlp_fused": lambda: ops.mlp(xm, f1, f2, act="gelu", residual=xm),
+        "pwk gemm + gelu": lambda: ops.dense(xg, cw, act="gelu"),
+        "conv3x3": lambda: ops.conv2d(xc3, cw3, pad=(1, 1, 1, 1), act="relu"),
+        "strict conv": lambda: ops.conv2d(xs32, cws, act="gelu"),
+    }
+
+
+def test_kernels_are_bit_exact_next_to_a_busy_matrix_pipe(report):
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import _abi
+    lib = _abi.lib()
+    sink = torch.zeros((16,), dtype=torch.float32, device="cuda")
+    flops = C.c_double(0.0)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    bad = {}
+    for name, fn in _victims().items():
+        ref = fn().clone()
+        torch.cuda.synchronize()
+        n_bad, worst = 0, 0.0
+        for _ in range(12):
+            with torch.cuda.stream(sb):      # 4 waves per SIMD of back-to-back v_mfma_f32_16x16x32_f16, nothing else
+                _abi.check(lib.vip_microbench_mfma_f16(sink.data_ptr(), 300, C.byref(flops), sb.cuda_stream), "vip_microbench_mfma_f16")
+            with torch.cuda.stream(sa):
+                out = fn()
+            torch.cuda.synchronize()
+            if not torch.equal(out, ref):
+                n_bad += 1
+                worst = max(worst, float((out.float() - ref.float()).abs().max()))
+        report(f"[concurrency] {name:26s} next to an MFMA-saturating kernel: {n_bad} of 12 launches differ from the solo result"
+               + (f" (max |d| {worst:.2e})" if n_bad else ""))
+        if n_bad:
+            bad[name] = (n_bad, worst)
+    assert not bad, f"results depend on the co-running kernel: {bad}"
+
+
+def test_pipelined_bench_steps_are_bit_reproducible(report):
+    """30 pipelined steps of the config-4 workload (three member streams, next step forked before the previous one is joined, mixed-size
+    batch): every member's scores bit-identical to a joined reference step"""
+    import vipcup_amd  # noqa: F401
+    from tests import _parity as P
+    from vipcup_amd import workloads
+    raws = [synth_jpeg(100 + i) for i in range(15)] + [synth_jpeg(149)]
+    wl = workloads.build("ensemble4", batch=16, jpegs=raws, models=[P.gpu_member(k) for k in workloads.member_list("ensemble4")])
+    wl.step()
+    wl.step()
+    ref = wl.member_scores.clone()
+    diffs = 0
+    for _ in range(30):
+        if wl.step(pipelined=True) is not None:
+            diffs += int(not torch.equal(wl.member_scores, ref))
+    wl.flush()
+    diffs += int(not torch.equal(wl.member_scores, ref))
+    report(f"[concurrency] ensemble4, 30 pipelined steps vs a joined step: {diffs} differ")
+    wl.close()
+    assert diffs == 0

@@ -1,4 +1,4 @@
-"""What do the wrong outputs of vip_window_attn_fwd_f16 under MFMA contention look like?  (follow-up of attn_race2.py)"""
+"""What do the wrong outputs of vip_window_attn_fwd_f16 under MFMA contention look like?  (follow-up of race_matrix.py)"""
 import ctypes as C
 import os
 import sys

@@ -1,7 +1,7 @@
 """Follow-up of tools/attn_race.py: WHICH co-resident kernels make vip_window_attn_fwd_f16 (and other kernels of this library) return
 wrong results?  Victim on stream A, aggressor on stream B, every victim result compared bit for bit with its own solo result.
 
-    python tools/attn_race2.py [--iters 40]
+    python tools/race_matrix.py [--iters 40]
 """
 import argparse
 import ctypes as C
@@ -18,8 +18,9 @@ from vipcup_amd import _abi, ops  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
-    ap.add_argument("--victims", default="attn14,attn7,mhsa,mlp_fused,se_gate,dwconv3,layernorm,gemm")
-    ap.add_argument("--aggressors", default="pwk_gelu,pwk_plain,gemm8p,pw_stream,conv3x3,mfma_only,copy16,layernorm,dwconv7,attn14")
+    ap.add_argument("--victims", default="attn14,attn7,attn14g,mhsa,mlp_fused,mlp_stream,se_gate,dwconv3,dwconv7,layernorm,gemm,gemm8p,"
+                                          "pw_stream,conv3x3,rows_gemm,gated,hilo,stem,sconv,sattn")
+    ap.add_argument("--aggressors", default="mfma_only,pwk_plain,pw_stream,conv3x3,gemm8p")
     a = ap.parse_args()
     g = torch.Generator().manual_seed(1)
 
@@ -58,7 +59,37 @@ def main():
     def st():
         return torch.cuda.current_stream().cuda_stream
 
+    qg14 = r(64, 196, 256)
+    qkv14g = r(64, 14, 14, 512)
+    xm2 = r(64 * 28 * 28, 192)
+    f1b = ops.make_dense_weight(torch.randn(192, 768, generator=g) / 14, torch.zeros(768))
+    f2b = ops.make_dense_weight(torch.randn(768, 192, generator=g) / 28, torch.zeros(192))
+    xr = r(256, 2048)
+    cwr = ops.make_dense_weight(torch.randn(2048, 512, generator=g) / 45, torch.zeros(512))
+    xgate = r(64, 14, 14, 960)
+    gate = torch.stack([torch.rand(64, 960, generator=g).to(torch.float16), torch.zeros(64, 960, dtype=torch.float16)], 1).cuda().contiguous()
+    cwgate = ops.make_conv_weight(torch.randn(1, 1, 960, 160, generator=g) / 31, torch.zeros(160))
+    xh = r(64, 56, 56, 24)
+    cwh = ops.make_conv_weight(torch.randn(1, 1, 24, 144, generator=g) / 5, torch.zeros(144), hilo=True)
+    xstem = r(64, 200, 200, 8)
+    cwstem = ops.make_conv_weight(torch.randn(3, 3, 8, 32, generator=g) / 8, torch.zeros(32))
+    with ops.precision("strict"):
+        cws = ops.make_conv_weight(torch.randn(1, 1, 256, 256, generator=g) / 16, torch.zeros(256))
+    xs32 = torch.randn(64, 14, 14, 256, generator=g).cuda()
+    qkvs = torch.randn(16, 14, 14, 768, generator=g).cuda()
     victims = {
+        "attn14g": lambda: ops.window_attention(qkv14g, qg14, tab14, 8, 14, 32 ** -0.5),
+        "mlp_stream": lambda: ops.mlp(xm2, f1b, f2b, act="gelu", residual=xm2),
+        "dwconv7": lambda: ops.dwconv2d(xd7, wd7, None, 7, 1, (3, 3, 3, 3)),
+        "gemm8p": lambda: ops.dense(xg1k, cw1k),
+        "pw_stream": lambda: ops.conv2d(xps, cwps, act="relu"),
+        "conv3x3": lambda: ops.conv2d(xc3, cwc3, pad=(1, 1, 1, 1), act="relu"),
+        "rows_gemm": lambda: ops.dense(xr, cwr, act="relu"),
+        "gated": lambda: ops.conv2d(xgate, cwgate, gate=gate),
+        "hilo": lambda: ops.conv2d(xh, cwh, act="silu"),
+        "stem": lambda: ops.conv2d(xstem, cwstem, stride=2, pad=(0, 1, 0, 1), act="silu"),
+        "sconv": lambda: ops.conv2d(xs32, cws, act="gelu"),
+        "sattn": lambda: ops.window_attention(qkvs, None, tab14, 8, 14, 32 ** -0.5),
         "attn14": lambda: ops.window_attention(qkv14, None, tab14, 8, 14, 32 ** -0.5),
         "attn7": lambda: ops.window_attention(qkv7, None, tab7, 2, 7, 32 ** -0.5),
         "mhsa": lambda: ops.mhsa(qkvm, 6, 0.125),

@@ -26,7 +26,7 @@
 #include "common.hpp"
 #include <stdlib.h>
 
-// CONCURRENCY NOTE (round 3, tools/stress_determinism.py -> bisect_determinism.py -> attn_race2.py).  Rounds 1-2 computed S^T with a
+// CONCURRENCY NOTE (round 3, tools/stress_determinism.py -> bisect_determinism.py -> race_matrix.py).  Rounds 1-2 computed S^T with a
 // zero C operand, then read the relative-position table from LDS and added it with v_pk_add_f32.  That form is bit-exact when the
 // kernel has the chip to itself and WRONG when waves of another MFMA-heavy kernel share its SIMDs (the ensemble runs its members on
 // several streams): with a pure-MFMA co-runner 39 of 40 launches returned a few (window, head, 16-query tile) blocks with
