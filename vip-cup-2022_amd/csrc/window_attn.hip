@@ -32,14 +32,16 @@
 // several streams): with a pure-MFMA co-runner 39 of 40 launches returned a few (window, head, 16-query tile) blocks with
 // deterministic wrong values (|d| up to 1.0), which is what made GCViT's scores differ between pipelined and joined bench steps.
 // What did NOT help: up to 128 wait states between the MFMAs and their consumers, every MFMA source operand in registers of its own
-// kept live to the end of the tile, s_setprio, 40 KB of extra LDS.  What does: the table values are read BEFORE the MFMAs, straight
-// into the accumulators, and go in as the MFMA's C operand - no LDS return lands and no packed add runs between the MFMAs and the
-// softmax (and the tile saves its 28 packed adds).  40 of 40 launches bit-identical under every co-runner, both window sizes.
+// kept live to the end of the tile, s_setprio, 40 KB of extra LDS.  What does: the table values are read straight into the
+// accumulators and go in as the MFMA's C operand - the "MFMA with C = 0, LDS read, v_pk_add_f32 on the MFMA result" sequence no
+// longer exists (and the tile saves its 28 packed adds).  40 of 40 launches bit-identical under every co-runner, both window
+// sizes, with or without scheduling fences around the MFMAs (profiles/r03_attn_race_*.log); speed unchanged (42.7 vs 42.5 us at L2).
 // WA_PV_OPERANDS_FIRST: the P.V MFMAs take all their operands (P^T fragments, V^T fragments) from registers that are complete before
 // the first of them issues (1), or convert / read them step by step between the MFMAs as rounds 1-2 did (0).
 #ifndef WA_PV_OPERANDS_FIRST
 #define WA_PV_OPERANDS_FIRST 1
 #endif
+
 
 namespace {
 
@@ -133,10 +135,8 @@ __device__ __forceinline__ void win_query_tile(const WinArgs& a, const U4H8& qfr
             const int row = t * 16 + l15;
             kf[t].u = *reinterpret_cast<const uint4*>(k_lds + row * Cfg::ROWB + k_slot(row, g) * 16);
         }
-        __builtin_amdgcn_sched_barrier(0);      // every LDS read above is issued before the first MFMA below
 #pragma unroll
         for (int t = 0; t < NKT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t].h, qfrag.h, acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
         float m = -1.0e30f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t) {
@@ -189,12 +189,10 @@ __device__ __forceinline__ void win_query_tile(const WinArgs& a, const U4H8& qfr
                         (__attribute__((address_space(3))) fp16x4_t*)(v_lds + row * Cfg::ROWB + half * 32 + tr_p * 8));
                 }
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < NKT / 2; ++s)
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfa[s][dt].v, pfa[s].h, o[dt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
 #else
 #pragma unroll
         for (int s = 0; s < NKT / 2; ++s) {
