@@ -319,6 +319,11 @@ int vip_tta_augment_f16(const void* x, void* y, const int32_t* flags, int B, int
  * wd f32 [k][k][Ce]; z f16 [B,Ho,Wo,Ce]; (pt, pl) = zero padding of the depthwise input.  vip_mbconv_expand_dw_supported:
  * Cin % 8 == 0, Cin <= 128, Ce % 32 == 0, k in {3, 5}, stride in {1, 2}.
  * ------------------------------------------------------------------------------------------ */
+/* EXPERIMENT (measured 0.4-0.8x the speed of the two launches it replaces): compiled only with VIP_BUILD_EXPERIMENTS=1; in the default
+ * library vip_mbconv_expand_dw_supported() is 0 for every shape and vip_mbconv_expand_dw_f16 returns VIP_ERR_UNSUPPORTED.
+ * vip_experiments_built() = 1 when the experimental kernels (this one, the depthwise convolution on the matrix cores behind
+ * VIP_DW_MFMA=1, the pipelined window attention behind VIP_ATTN_PIPE=1) are in the library. */
+int vip_experiments_built(void);
 int vip_mbconv_expand_dw_supported(int Cin, int Ce, int k, int stride);
 int vip_mbconv_expand_dw_f16(const void* x, const void* we, const void* we_lo, const float* be, const float* wd, const float* bd,
                              void* z, int B, int H, int W, int Cin, int Ce, int ldw, int k, int stride, int pt, int pl, int Ho,

@@ -22,6 +22,17 @@ def _ops():
     return ops
 
 
+def _experiments():
+    """the experimental kernels (VIP_BUILD_EXPERIMENTS=1 python vip-cup-2022_amd/build.py --force) are not in the default library"""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import _abi
+    return bool(_abi.lib().vip_experiments_built())
+
+
+needs_experiments = pytest.mark.skipif("not __import__('torch').cuda.is_available() or not _experiments()",
+                                       reason="experimental kernel: build with VIP_BUILD_EXPERIMENTS=1")
+
+
 def h(t):
     """fp16-rounded fp32 copy (CPU) of t"""
     return t.to(torch.float16).to(torch.float32)
@@ -363,6 +374,7 @@ def test_dwconv(k, s, C, H, report):
 # the matrix-core depthwise kernel (k 7 / 5, stride 1, C % 16 == 0): tile tails in both axes, maps smaller than a tile, several
 # tiles per image and several images per band, asymmetric padding (TF SAME on even sizes is symmetric here; VALID = no padding),
 # every activation epilogue; the filter is fp32 at the boundary and the kernel carries it as hi + lo fp16 - checked to 1e-3 of |y|max
+@needs_experiments
 @pytest.mark.parametrize("k,C,H,W,B,pad,act", [(7, 96, 35, 21, 3, (3, 3, 3, 3), None), (7, 32, 7, 7, 5, (3, 3, 3, 3), "gelu"),
                                                (7, 16, 50, 17, 2, (0, 0, 0, 0), "relu"), (7, 48, 16, 16, 9, (2, 4, 1, 5), "silu"),
                                                (5, 336, 14, 14, 2, (2, 2, 2, 2), "silu"), (5, 16, 33, 40, 3, (1, 3, 4, 0), None),
@@ -497,6 +509,7 @@ def test_gap_ln_dense_head(B, HW, C, N, report):
 
 # MBConv expand 1x1 + depthwise in one launch: every (k, stride), the three slab widths (64 / 48 / 32), K below / at a k-step boundary,
 # two-term expand weights, tile tails, maps smaller than a tile, TF SAME padding on even and odd sizes (asymmetric for stride 2)
+@needs_experiments
 @pytest.mark.parametrize("k,s,Cin,Ce,H,W,B,hilo", [(3, 1, 32, 192, 13, 11, 2, True), (3, 2, 24, 144, 20, 20, 2, True),
                                                    (5, 1, 56, 336, 9, 17, 3, False), (5, 2, 32, 192, 15, 15, 2, True),
                                                    (3, 2, 56, 336, 7, 7, 3, False), (5, 1, 112, 672, 6, 6, 2, False),
@@ -616,6 +629,7 @@ def test_window_attention(ws, heads, nW, global_q, report):
     check(report, f"window_attn ws{ws} heads{heads} nW{nW} global={global_q}", got, ref, tol=3e-3)
 
 
+@needs_experiments
 @pytest.mark.parametrize("B,heads,nW,global_q", [(128, 8, 1, False), (131, 8, 1, True), (40, 8, 2, False), (70, 4, 2, True)])
 def test_window_attention_pipelined(B, heads, nW, global_q, report):
     """ws 14 with >= 1024 (window, head) items: the persistent LDS-DMA kernel (window_attn_pipe_kernel) - 2..5 items per workgroup,

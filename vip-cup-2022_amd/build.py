@@ -16,12 +16,18 @@ OBJ_DIR = os.path.join(HERE, "build")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
+# Experiments - kernels that measured slower than what they would replace - are only compiled on request:
+#   VIP_BUILD_EXPERIMENTS=1 python vip-cup-2022_amd/build.py --force
+EXPERIMENTS = os.environ.get("VIP_BUILD_EXPERIMENTS", "0") == "1"
+EXPERIMENT_SOURCES = {"dwconv_mfma.hip", "mbconv_fused.hip"}
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
-            "-Wno-unused-result", "-ffp-contract=fast"] + os.environ.get("VIP_EXTRA_CXXFLAGS", "").split()
+            "-Wno-unused-result", "-ffp-contract=fast", f"-DVIP_BUILD_EXPERIMENTS={int(EXPERIMENTS)}"] \
+    + os.environ.get("VIP_EXTRA_CXXFLAGS", "").split()
 
 
 def _sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                  if f.endswith((".hip", ".cpp")) and (EXPERIMENTS or f not in EXPERIMENT_SOURCES))
 
 
 def _deps_mtime():
@@ -31,7 +37,7 @@ def _deps_mtime():
 
 
 def _compile(src, force):
-    obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+    obj = os.path.join(OBJ_DIR, os.path.basename(src) + (".exp.o" if EXPERIMENTS else ".o"))
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= _deps_mtime()):
         return obj

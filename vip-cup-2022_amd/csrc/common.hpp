@@ -6,6 +6,13 @@
 #include <stdarg.h>
 #include "vipcup_hip.h"
 
+// Experiments: kernels that were built, verified and measured SLOWER than what they would replace (the depthwise convolution on the
+// matrix cores, the fused MBConv front half, the pipelined persistent window attention) are compiled only with
+// VIP_BUILD_EXPERIMENTS=1 (build.py); the default library holds what the default step launches.
+#ifndef VIP_BUILD_EXPERIMENTS
+#define VIP_BUILD_EXPERIMENTS 0
+#endif
+
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));

@@ -351,6 +351,11 @@ extern "C" int vip_layernorm_f16(const void* x, const float* gamma, const float*
     return vip_launch_status("vip_layernorm_f16");
 }
 
+#if !VIP_BUILD_EXPERIMENTS
+// the matrix-core depthwise experiment (dwconv_mfma.hip) is not in this build: "not handled here"
+int vip_dwconv_mfma(const void*, const float*, const float*, void*, int, int, int, int, int, int, int, int, int, int, hipStream_t) { return 1; }
+#endif
+
 extern "C" int vip_dwconv2d_nhwc_f16(const void* x, const float* w, const float* bias, void* y, int B, int H, int W,
                                      int C, int k, int stride, int pt, int pl, int Ho, int Wo, int act, void* stream) {
     VIP_REQUIRE(x && w && y, VIP_ERR_BAD_ARG, "vip_dwconv2d_nhwc_f16: null pointer");

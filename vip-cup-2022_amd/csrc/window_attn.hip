@@ -367,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_kernel(WinArgs a) {
     }
 }
 
+#if VIP_BUILD_EXPERIMENTS   // experiments are kept out of the default build (VIP_BUILD_EXPERIMENTS=1 python build.py): DESIGN.md section 3
 // ---- ws = 14, persistent + pipelined ----------------------------------------------------------------------------------
 // The kernel above is a load phase followed by a compute phase per workgroup; with HBM time (~18 us for the 103 MB of level 2
 // at B = 256) about equal to the VALU + MFMA time (~20 us) and every resident workgroup in the same phase, the two add up
@@ -544,6 +545,8 @@ int launch_win_pipe(const WinArgs& a, hipStream_t s) {
     return vip_launch_status("vip_window_attn_fwd_f16(pipe)");
 }
 
+#endif  // VIP_BUILD_EXPERIMENTS
+
 template <int WS, int P, int LOG2P, int WPI>
 int launch_win(const WinArgs& a, hipStream_t s) {
     using Cfg = WinCfg<WS, P, LOG2P, WPI>;
@@ -585,9 +588,11 @@ extern "C" int vip_window_attn_fwd_f16(const void* qkv, const void* q_global, co
     // ws 14: the pipelined persistent kernel is opt-in (VIP_ATTN_PIPE=1, read per call): measured 44.6 us against 42.5 us for the
     // one-item kernel at B = 256 - the kernel is VALU-bound (softmax), not fetch-bound, and 4 resident workgroups per CU hide the
     // per-wave MFMA -> VALU -> MFMA chains better than 2 pipelined ones
+#if VIP_BUILD_EXPERIMENTS
     const char* pipe_env = getenv("VIP_ATTN_PIPE");
     const int pipe = pipe_env ? atoi(pipe_env) : 0;
     if (pipe && items >= 1024 && items % heads == 0 && 2L * B * Hp * Wp * nq * C < 0x7FFF0000L)
         return launch_win_pipe<14, 16, 4>(a, (hipStream_t)stream);
+#endif
     return launch_win<14, 16, 4, 4>(a, (hipStream_t)stream);
 }
