@@ -46,14 +46,30 @@ def vit_attention(p, name, x, heads):
     return R.dense(o, p[f"{name}/proj/kernel"], p[f"{name}/proj/bias"])
 
 
-def vit_forward_tokens(p, x, name, nb_blocks=None, collect=None):
-    """ViT.forward_features up to norm (vit.py:414-441)"""
+def interpolate_pos_embeddings(pos_embed, src_grid, tgt_grid, nb_tokens=1):
+    """tfimm/layers/transformers.py:13-47: [1, N, D] -> [1, nb_tokens + gh*gw, D] via tf.image.resize(bicubic) of the patch part"""
+    if tuple(src_grid) == tuple(tgt_grid):
+        return pos_embed
+    D = pos_embed.shape[-1]
+    src = pos_embed[0, nb_tokens:].reshape(src_grid[0], src_grid[1], D)
+    tgt = R.resize_bicubic(src, tgt_grid[0], tgt_grid[1]).reshape(1, tgt_grid[0] * tgt_grid[1], D)
+    return torch.cat([pos_embed[:, :nb_tokens], tgt], dim=1)
+
+
+def vit_forward_tokens(p, x, name, nb_blocks=None, collect=None, interpolate_input=False):
+    """ViT.forward_features up to norm (vit.py:414-441); ``interpolate_input`` (vit.py:58,425-433): position embeddings resampled
+    to the patch grid of the input"""
     D, nb, heads, ps = VIT[name]
     nb = nb_blocks or nb
     B = x.shape[0]
     t = R.conv2d(x, p["patch_embed/proj/kernel"], p["patch_embed/proj/bias"], ps)  # PatchEmbeddings, VALID
+    grid = (t.shape[1], t.shape[2])
     t = t.reshape(B, -1, D)
-    t = torch.cat([p["cls_token"].expand(B, -1, -1), t], dim=1) + p["pos_embed"]
+    pos = p["pos_embed"]
+    if interpolate_input:
+        g0 = int(round((pos.shape[1] - 1) ** 0.5))
+        pos = interpolate_pos_embeddings(pos, (g0, g0), grid)
+    t = torch.cat([p["cls_token"].expand(B, -1, -1), t], dim=1) + pos
     for j in range(nb):
         b = f"blocks/{j}"
         t = t + vit_attention(p, f"{b}/attn", _ln(p, f"{b}/norm1", t), heads)   # ViTBlock.call (vit.py:214-227)
@@ -63,9 +79,9 @@ def vit_forward_tokens(p, x, name, nb_blocks=None, collect=None):
     return _ln(p, "norm", t)
 
 
-def vit_logits(p, x, name, nb_blocks=None):
+def vit_logits(p, x, name, nb_blocks=None, interpolate_input=False):
     """head(norm(x)[:, 0]) (vit.py:441-461)"""
-    t = vit_forward_tokens(p, x, name, nb_blocks)
+    t = vit_forward_tokens(p, x, name, nb_blocks, interpolate_input=interpolate_input)
     return R.dense(t[:, 0], p["head/kernel"], p["head/bias"])
 
 

@@ -87,3 +87,28 @@ def test_convnext(name, report):
     torch.cuda.synchronize()
     ze = _model_check(report, name, z, z_ref, ca, cb)
     assert ze < 3e-3 * max(1.0, z_ref.abs().max().item())
+
+
+def test_vit_interpolate_input(report):
+    """ViTConfig.interpolate_input (vit.py:58,425-433; layers/transformers.py:13-47): a 224-pixel ViT scored at 192 x 192 (12 x 12 patch
+    grid, 145 tokens) with its position embeddings resampled - fast and strict precision against the oracle graph."""
+    import dataclasses
+    import vipcup_amd  # noqa: F401
+    from oracle import tfimm_ref
+    from vipcup_amd import ops, tfimm_models as tm
+    key = "vit_tiny_patch16_224"
+    cfg = dataclasses.replace(tm.VIT_CONFIGS[key], interpolate_input=True)
+    p = tm.vit_synth_params(cfg, 1008)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand((3, 192, 192, 3), generator=g)
+    with torch.no_grad():
+        z = tfimm_ref.vit_logits(p, x, key, interpolate_input=True)
+    for mode, tol in (("fast", 5e-3), ("strict", 2e-5)):
+        with ops.precision(mode):
+            m = tm.ViT(p, cfg)
+        got = m.logits(ops.to_device_nhwc8(x, dtype=ops.act_dtype(mode))).cpu()
+        d = (got - z).abs().max().item()
+        report(f"[tfimm] {key} at 192x192 with interpolate_input, {mode}: max|dz| {d:.2e} (logit std {z.std().item():.3f})")
+        assert d <= tol
+    with pytest.raises(ValueError):      # the default configuration refuses another input size, as the reference's fixed pos_embed add does
+        tm.ViT(p, tm.VIT_CONFIGS[key]).logits(ops.to_device_nhwc8(x))

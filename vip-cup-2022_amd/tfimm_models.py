@@ -41,6 +41,7 @@ class ViTConfig:
     mlp_ratio: float = 4.0
     qkv_bias: bool = True
     nb_classes: int = 1
+    interpolate_input: bool = False     # vit.py:58: adapt the position embeddings to the input's patch grid at run time
 
     @property
     def grid_size(self):
@@ -49,6 +50,55 @@ class ViTConfig:
     @property
     def nb_patches(self):
         return self.grid_size[0] * self.grid_size[1]
+
+
+def _tf_bicubic_taps(out_size: int, in_size: int):
+    """indices [out, 4] and fp32 weights [out, 4] of tf.image.resize(method="bicubic", antialias=False) along one axis - the legacy
+    kernel with half-pixel centres: Keys a = -0.5, the fractional offset quantised to the 1024-entry coefficient table
+    (vip_bicubic_table_f32, the table the image pipeline uses on the GPU), taps outside the image dropped and the rest renormalised"""
+    import ctypes as C
+    import numpy as np
+    from . import _abi
+    table = np.zeros((1025 * 2,), dtype=np.float32)
+    _abi.check(_abi.lib().vip_bicubic_table_f32(table.ctypes.data_as(C.c_void_p)), "vip_bicubic_table_f32")
+    f32 = np.float32
+    scale = f32(in_size) / f32(out_size)
+    loc = (np.arange(out_size, dtype=f32) + f32(0.5)) * scale - f32(0.5)
+    fl = np.floor(loc)
+    off = np.rint((loc - fl) * f32(1024)).astype(np.int64)            # lrintf: round half to even
+    w = np.stack([table[off * 2 + 1], table[off * 2], table[(1024 - off) * 2], table[(1024 - off) * 2 + 1]], 1)
+    want = fl.astype(np.int64)[:, None] + np.arange(-1, 3)[None, :]
+    idx = np.clip(want, 0, in_size - 1)
+    w = np.where(idx == want, w, f32(0)).astype(f32)
+    ssum = ((w[:, 0] + w[:, 1]) + w[:, 2]) + w[:, 3]
+    ok = np.abs(ssum) >= f32(1000.0) * f32(1.17549435e-38)
+    w = np.where(ok[:, None], w * (f32(1) / np.where(ok, ssum, f32(1)))[:, None], w).astype(f32)
+    return idx, w
+
+
+def interpolate_pos_embeddings(pos_embed: torch.Tensor, src_grid, tgt_grid, nb_tokens: int = 1) -> torch.Tensor:
+    """tfimm/layers/transformers.py:13-47: position embeddings ``[N, D]`` of a ``src_grid`` patch grid (the first ``nb_tokens`` rows
+    belong to the class token(s) and are kept) resampled to ``tgt_grid`` with tf.image.resize(bicubic).  Host arithmetic in fp32 at
+    load time / first use of an input size (a [gh, gw, D] array of a few hundred KB), the same operation order as the GPU image
+    resize: along x on the four source rows first, then along y, each as ((v0 w0 + v1 w1) + v2 w2) + v3 w3."""
+    import numpy as np
+    if tuple(src_grid) == tuple(tgt_grid):
+        return pos_embed
+    pe = pos_embed.detach().cpu().to(torch.float32).numpy()
+    D = pe.shape[-1]
+    src = pe[nb_tokens:].reshape(src_grid[0], src_grid[1], D)
+    iy, wy = _tf_bicubic_taps(tgt_grid[0], src_grid[0])
+    ix, wx = _tf_bicubic_taps(tgt_grid[1], src_grid[1])
+    rows = None
+    for t in range(4):
+        term = src[:, ix[:, t], :] * wx[None, :, t, None]
+        rows = term if rows is None else rows + term
+    out = None
+    for t in range(4):
+        term = rows[iy[:, t], :, :] * wy[:, t, None, None]
+        out = term if out is None else out + term
+    out = np.concatenate([pe[:nb_tokens], out.reshape(tgt_grid[0] * tgt_grid[1], D).astype(np.float32)], 0)
+    return torch.from_numpy(out)
 
 
 def variant(cfg, overrides: Dict):
@@ -101,6 +151,9 @@ class ViT:
         self.patch = ops.make_conv_weight(p["patch_embed/proj/kernel"], p["patch_embed/proj/bias"], device=dev, pad_cin_to=8)
         self.cls = p["cls_token"].reshape(D).to(dev, ops.act_dtype()).contiguous()      # stored like an activation (fp32 when strict)
         self.pos = p["pos_embed"].reshape(-1, D).to(dev, ops.act_dtype()).contiguous()
+        self._pos32 = p["pos_embed"].reshape(-1, D).to(torch.float32)                  # host copy: source of interpolated grids
+        self._pos_by_grid = {tuple(cfg.grid_size): self.pos}
+        self._act_dtype, self._dev = ops.act_dtype(), dev
         self.blocks = []
         for j in range(cfg.nb_blocks):
             b = f"blocks/{j}"
@@ -118,12 +171,17 @@ class ViT:
     def features(self, x, collect=None):
         """ViT.forward_features (vit.py:414-451) up to the final norm; returns [B, N, D] tokens."""
         cfg = self.cfg
-        assert x.shape[-1] == 8 and tuple(x.shape[1:3]) == tuple(cfg.input_size), \
-            "interpolate_input=False (vit.py:58): input must equal cfg.input_size"
+        assert x.shape[-1] == 8
+        if not cfg.interpolate_input and tuple(x.shape[1:3]) != tuple(cfg.input_size):
+            raise ValueError(f"{cfg.name}: interpolate_input=False (vit.py:58): the input must be {cfg.input_size}, got {tuple(x.shape[1:3])}")
         B = x.shape[0]
         ps = cfg.patch_size
-        pe = ops.conv2d(x, self.patch, stride=ps)                       # PatchEmbeddings (transformers.py:131-139)
-        t = ops.vit_tokens(pe.reshape(B, cfg.nb_patches, cfg.embed_dim), self.cls, self.pos)
+        pe = ops.conv2d(x, self.patch, stride=ps)                       # PatchEmbeddings (transformers.py:131-139), VALID: floor(H / ps)
+        grid = (pe.shape[1], pe.shape[2])
+        if grid not in self._pos_by_grid:                                # vit.py:425-433: embeddings resampled to the input's patch grid
+            pos = interpolate_pos_embeddings(self._pos32, cfg.grid_size, grid, nb_tokens=1)
+            self._pos_by_grid[grid] = pos.to(self._dev, self._act_dtype).contiguous()
+        t = ops.vit_tokens(pe.reshape(B, grid[0] * grid[1], cfg.embed_dim), self.cls, self._pos_by_grid[grid])
         scale = (cfg.embed_dim // cfg.nb_heads) ** -0.5
         for blk in self.blocks:                                          # ViTBlock.call (vit.py:214-227)
             qkv = ops.dense(blk["n1"](t), blk["qkv"])
