@@ -38,7 +38,7 @@ with h5py.File(dst, "w") as top:
     f.attrs["backend"] = "tensorflow"
     f.attrs["keras_version"] = "2.8.0"
     for layer, names in layers.items():
-        g = f.create_group(layer)
+        g = f.require_group(layer)          # a layer whose name is the prefix of another (gcvit: levels/0/blocks/0/attn[/qkv]) already exists
         put_attr(g, "weight_names", [n + ":0" for n in names])
         for n in names:
             g.create_dataset(n + ":0", data=arrays[n])
