@@ -715,6 +715,164 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
 }
 
 
+#if VIP_BUILD_EXPERIMENTS
+// ---- the direct kernel with the activation fragments requested TWO k-chunks ahead (round 3) ----------------------------------
+// EXPERIMENT (VIP_BUILD_EXPERIMENTS=1, selected per call with VIP_PWK_PF2=1) - a NEGATIVE result, kept for the record.
+// PMC of pwk_direct_kernel<2, false, 4> on its typical shapes (profiles/r03_pwk_pmc_*.txt): the matrix pipe is busy 30 % of the time,
+// a wave spends 47-62 % of its life in s_waitcnt, and a k-chunk takes ~6 000 cycles against 1 024 cycles of MFMAs.  Hypothesis: the
+// loop is a chain of memory round trips with too few bytes in flight.  This variant halves the wave tile to 32 pixels x 128 channels
+// (64 accumulator registers instead of 128) and spends the registers on a second activation register set: the fragments of chunk
+// kc + 2 are requested while chunk kc is multiplied (the k-loop is unrolled by two so that a chunk's register set is a compile-time
+// choice), 3 waves per SIMD instead of 2.  Bit-identical to the default kernel and SLOWER on 12 of 16 ensemble shapes (0.81-1.12x,
+// sum 680 vs 642 us; profiles/r03_pwk_deep_prefetch_ab.log): the 128-pixel block tile doubles the weight staging and the L2 -> CU
+// traffic per output (~7 TB/s chip-wide either way), which costs more than the extra loads in flight buy.
+template <int NG>
+__global__ __launch_bounds__(256, 3) void pwk_direct2_kernel(ConvArgs a, int mode) {
+    constexpr int PT = 2;
+    constexpr int NB = 64 * NG, ROWB = 160;
+    constexpr int STAGE = NB * ROWB;
+    constexpr int W_IT = NB / 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mb = bid / a.n_blocks, nb = bid - mb * a.n_blocks;
+    const int m0 = mb * (64 * PT) + wave * (16 * PT);
+    const int n0 = nb * NB;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + a.cin_off), 0, (unsigned)min((long)0xFFFFFFF0L, a.x_span_bytes - 2L * a.cin_off), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_res =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (unsigned)a.res_span_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (unsigned)a.y_span_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_bias =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)(a.bias_elems * 4) : 0u, 0x00020000);
+
+    const int wc = tid & 7;
+    unsigned w_off[W_IT];
+    int w_lds[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int j = (tid >> 3) + 32 * i;
+        const int t = (j >> 4) & 3, r = j & 15;
+        const int ch = n0 + (j & ~63) + (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3);
+        w_off[i] = ch < a.Cout_g ? (unsigned)((ch * a.ldw + wc * 8) * 2) : OOB;
+        w_lds[i] = j * ROWB + wc * 16;
+    }
+    unsigned x_off[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m0 + p * 16 + l15;
+        x_off[p] = m < a.M ? (unsigned)((m * a.ldx + lq * 8) * 2) : 0xFFFF0000u;
+    }
+    const int nk = (a.K + 63) >> 6;
+
+    uint4 wst[W_IT];
+    auto load_w = [&](int kc) {
+        const bool ok = kc * 64 + wc * 8 < a.K;
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i)
+            wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? w_off[i] + kc * 128 : OOB, 0, 0));
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + w_lds[i]) = wst[i];
+    };
+    U4H8 xf[2][2][PT];                                         // [register set = chunk parity][k-step][pixel tile]
+    auto load_x = [&](U4H8 (&dst)[PT], int kc, int ks) {
+        const bool ok = kc * 64 + ks * 32 + lq * 8 < a.K;       // also false for every chunk past the end of K: zeros, no traffic
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+            dst[p].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + kc * 128 + ks * 64 : OOB, 0, 0));
+    };
+
+    f32x4 acc[NG][PT][4];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + g * 64 + (nt >> 1) * 32 + lq * 8 + (nt & 1) * 4;
+            const f32x4 bv = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_bias, n < a.Cout_g ? (unsigned)(n * 4) : OOB, 0, 0));
+#pragma unroll
+            for (int p = 0; p < PT; ++p) acc[g][p][nt] = bv;
+        }
+
+    load_w(0);
+    load_x(xf[0][0], 0, 0);
+    load_x(xf[0][1], 0, 1);
+    load_x(xf[1][0], 1, 0);
+    load_x(xf[1][1], 1, 1);
+    store_w(0);
+    __syncthreads();
+
+    auto compute = [&](int buf, const U4H8 (&xs)[PT], int ks) {
+        const char* ws = smem + buf * STAGE + l15 * ROWB + lq * 16 + ks * 64;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            U4H8 wf[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + (g * 64 + nt * 16) * ROWB);
+            if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+                    acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xs[p].h, acc[g][p][nt], 0, 0, 0);
+            if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+        }
+    };
+    // one chunk on register set SET (compile time): its fragments are re-requested for chunk kc + 2 as soon as their MFMAs are issued
+#define VIP_PWK2_CHUNK(SET, KC)                               \
+    {                                                         \
+        const int buf = (KC) & 1;                             \
+        load_w((KC) + 1);                                     \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        compute(buf, xf[SET][0], 0);                          \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        load_x(xf[SET][0], (KC) + 2, 0);                      \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        compute(buf, xf[SET][1], 1);                          \
+        __builtin_amdgcn_sched_barrier(0);                    \
+        load_x(xf[SET][1], (KC) + 2, 1);                      \
+        store_w(buf ^ 1);                                     \
+        __syncthreads();                                      \
+    }
+    for (int kc = 0; kc < nk; kc += 2) {
+        VIP_PWK2_CHUNK(0, kc)
+        if (kc + 1 < nk) VIP_PWK2_CHUNK(1, kc + 1)            // wave-uniform: nk comes from a kernel argument
+    }
+#undef VIP_PWK2_CHUNK
+
+    int m_base = m0 + l15, n_lane = n0 + lq * 8;
+    asm volatile("" : "+v"(m_base), "+v"(n_lane));
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int n_first = n_lane + g * 64;
+        switch (mode) {
+            case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+        }
+    }
+}
+
+#endif  // VIP_BUILD_EXPERIMENTS
+
 template <int NG, int WN, bool IM2COL>
 __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(ConvArgs a, int mode) {
     // IM2COL: the same kernel for k x k / strided / grouped convolutions - only the activation staging changes (each
@@ -954,6 +1112,12 @@ int launch_pwk_direct(const ConvArgs& a0, int mode, hipStream_t s) {
     static const int fill = getenv("VIP_PWK_FILL") ? atoi(getenv("VIP_PWK_FILL")) : 256;
     const long wg256 = (long)((a.M + 255) / 256) * a.n_blocks;
     if (wg256 < fill) launch_pwk_direct_pt<NG, 1>(a, mode, s);
+#if VIP_BUILD_EXPERIMENTS
+    else if (!a.gate && getenv("VIP_PWK_PF2") && atoi(getenv("VIP_PWK_PF2"))) {     // the two-chunks-ahead experiment (read per call)
+        a.m_blocks = (a.M + 127) / 128;
+        hipLaunchKernelGGL((pwk_direct2_kernel<NG>), dim3((unsigned)(a.m_blocks * a.n_blocks)), dim3(256), 0, s, a, mode);
+    }
+#endif
     else launch_pwk_direct_pt<NG, 4>(a, mode, s);
     return vip_launch_status("vip_conv2d_nhwc_f16(pwk-direct)");
 }
