@@ -374,6 +374,13 @@ int vip_ensemble_mean_f32(const float* scores, float* mean, int M, int n, long l
  * ------------------------------------------------------------------------------------------ */
 int vip_conv2d_nhwc_s32(const float* x, const float* w, const float* bias, const float* residual, float* y,
                         const vip_conv_desc* d, void* stream);
+/* vip_conv2d_nhwc_s32 at 2.7x the matrix rate: every f32 operand is the sum of three bf16 terms (exact: 8 + 8 + 8 bits, f32's exponent
+ * range) and the product keeps the six partial products down to 2^-16 of the leading one on v_mfma_f32_16x16x32_bf16 with f32
+ * accumulation - what is dropped is <= 3 * 2^-24 of each product, the same results as the f32-MFMA entry point to f32 round-off.
+ * w_planes = the weights pre-split: three bf16 planes [3][Cout][ldwp] (ldwp % 8 == 0, zero padded), w = p0 + p1 + p2; activations are
+ * split inside the kernel.  d->ldw is ignored; everything else as vip_conv2d_nhwc_s32.  The default of the STRICT path. */
+int vip_conv2d_nhwc_s32x(const float* x, const void* w_planes, int ldwp, const float* bias, const float* residual, float* y,
+                         const vip_conv_desc* d, void* stream);
 int vip_dwconv2d_nhwc_s32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int k,
                           int stride, int pt, int pl, int Ho, int Wo, int act, void* stream);
 int vip_layernorm_s32(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps, void* stream);

@@ -58,9 +58,12 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:9]))
-def test_conv2d_strict(case, report):
+def test_conv2d_strict(case, gemm, report, monkeypatch):
+    """both STRICT GEMM arithmetics: three-term bf16 splits on six bf16 MFMAs (the default) and the f32-input MFMA"""
     ops = _ops()
+    monkeypatch.setattr(ops, "STRICT_GEMM", gemm)
     B, H, W, Cin, Cout, k, s, pad, groups, act, use_res = case
     g = torch.Generator().manual_seed(hash(case[:9]) % (2 ** 31))
     x = torch.randn(B, H, W, Cin, generator=g)
@@ -77,7 +80,7 @@ def test_conv2d_strict(case, report):
     got = ops.conv2d(dev(x), cw, stride=s, pad=pad, act=act, residual=None if res is None else dev(res))
     torch.cuda.synchronize()
     assert got.dtype == torch.float32
-    check(report, f"conv2d {case}", got, ref)
+    check(report, f"conv2d[{gemm}] {case}", got, ref)
 
 
 def test_conv2d_strict_channel_slices_and_gate(report):

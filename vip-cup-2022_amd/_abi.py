@@ -79,6 +79,7 @@ SIGNATURES = {
     "vip_vit_tokens_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     # STRICT precision path (fp32 storage, fp32 arithmetic): csrc/strict_conv.hip, csrc/strict_ops.hip
     "vip_conv2d_nhwc_s32": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
+    "vip_conv2d_nhwc_s32x": (_i, [_vp, _vp, _i, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
     "vip_dwconv2d_nhwc_s32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
     "vip_layernorm_s32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "vip_pool2d_nhwc_s32": (_i, [_vp, _vp] + [_i] * 13 + [_vp]),

@@ -203,39 +203,285 @@ int launch_sconv(const SConvArgs& a, hipStream_t s) {
     return vip_launch_status("vip_conv2d_nhwc_s32");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same convolution with every fp32 operand split into THREE bf16 terms (x = b0 + b1 + b2 exactly: 8 + 8 + 8 significant bits) and
+// the products kept down to 2^-16 of the leading one: x w ~= b0 c0 + (b0 c1 + b1 c0) + (b1 c1 + b0 c2 + b2 c0) - six
+// v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block, f32 accumulate.  What is dropped (b1 c2 + b2 c1 + b2 c2) is <= 3 * 2^-24 of the
+// product: f32-quality results (tests/test_gpu_strict.py holds it to the same 2e-5 as the f32-MFMA kernel) at 16 / 6 = 2.7 x the matrix
+// rate of v_mfma_f32_32x32x2_f32, and with bf16's f32 exponent range there is nothing to scale and nothing that can overflow.
+// Weights arrive pre-split (three bf16 planes [3][Cout][ldw], made once at load time by ops.make_conv_weight); activations are split
+// on their way into LDS (v_cvt_pk_bf16_f32 + two exact f32 subtractions per term).  Block tile (32 TCHW x 2) channels x 128 pixels x 32
+// k, 4 waves as 2 x 2, one LDS stage of three planes per operand (rows of 64 B + 16 B pad: conflict-free ds_read_b128), the next chunk
+// prefetched into registers while the current one is multiplied; weights are the MFMA A operand as in sconv_kernel (a lane ends
+// up with 4 consecutive channels of one pixel).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int S6_ROWB = 80;          // LDS bytes per row of a plane: 32 bf16 + 16 B pad
+
+struct SConv6Args {
+    SConvArgs c;
+    const unsigned short* wp;        // [3][Cout_total][ldwp] bf16
+    long plane_stride;               // elements between planes
+    int ldwp;
+};
+
+__device__ __forceinline__ unsigned s6_pk(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+// 8 consecutive f32 -> three uint4 of 8 bf16 each (planes 0, 1, 2)
+__device__ __forceinline__ void s6_split8(const f32x4& lo, const f32x4& hi, uint4& p0, uint4& p1, uint4& p2) {
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    unsigned o0[4], o1[4], o2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        const unsigned q0 = s6_pk(a, b);
+        const float ra = a - __builtin_bit_cast(float, q0 << 16), rb = b - __builtin_bit_cast(float, q0 & 0xffff0000u);
+        const unsigned q1 = s6_pk(ra, rb);
+        const float sa = ra - __builtin_bit_cast(float, q1 << 16), sb = rb - __builtin_bit_cast(float, q1 & 0xffff0000u);
+        o0[i] = q0;
+        o1[i] = q1;
+        o2[i] = s6_pk(sa, sb);
+    }
+    p0 = make_uint4(o0[0], o0[1], o0[2], o0[3]);
+    p1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
+}
+
+template <int TCHW>                  // 16-channel tiles per wave: 4 (block = 128 channels) or 2 (64 channels)
+__global__ __launch_bounds__(256, 2) void sconv6_kernel(SConv6Args aa) {
+    const SConvArgs& a = aa.c;
+    constexpr int TCH = 32 * TCHW, TPX = 128;
+    constexpr int PLANE_A = TCH * S6_ROWB, PLANE_B = TPX * S6_ROWB;
+    __shared__ __attribute__((aligned(16))) char smem[3 * PLANE_A + 3 * PLANE_B];
+    char* sA = smem;
+    char* sB = smem + 3 * PLANE_A;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int wc = wave & 1, wp_ = wave >> 1;
+    const int g = blockIdx.z;
+    const int ch0 = blockIdx.y * TCH;
+    const long px0 = (long)blockIdx.x * TPX;
+
+    // staging roles: 8 consecutive k (index kq, 0..3) of rows r0 + 64 i
+    const int kq = tid & 3, r0 = tid >> 2;
+    constexpr int LA = (TCH + 63) / 64, LB = TPX / 64;
+    long wrow[LA];
+    bool wok[LA];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        const int n = ch0 + r0 + 64 * i;
+        wok[i] = (r0 + 64 * i < TCH) && n < a.cout_g;
+        wrow[i] = (long)(g * a.cout_g + (wok[i] ? n : 0)) * aa.ldwp;
+    }
+    long xbase[LB];
+    int hi0[LB], wi0[LB];
+    bool pok[LB];
+    const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        const long m = px0 + r0 + 64 * i;
+        pok[i] = m < a.M;
+        const long mm = pok[i] ? m : 0;
+        const int b = (int)(mm / HoWo);
+        const int rem = (int)(mm - (long)b * HoWo);
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        hi0[i] = ho * a.sh - a.pt;
+        wi0[i] = wo * a.sw - a.pl;
+        xbase[i] = (long)b * a.H * a.W;
+    }
+    const int cbase = a.cin_off + g * a.cin_g;
+    const bool pointwise = a.kh == 1 && a.kw == 1;
+
+    uint4 ra[LA][3];
+    f32x4 rb[LB][2];
+    auto fetch = [&](int k0) {
+        const int k = k0 + 8 * kq;
+        const bool kok = k < a.K;            // weight planes are zero-padded to a multiple of 8 k: a group is in or out as a whole
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                ra[i][p] = make_uint4(0, 0, 0, 0);
+                if (kok && wok[i]) ra[i][p] = *reinterpret_cast<const uint4*>(aa.wp + p * aa.plane_stride + wrow[i] + k);
+            }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {        // the two 4-k halves of the group may belong to different filter taps
+            const int kh_ = k + 4 * h;
+            const bool hok = kh_ < a.K;
+            int c = kh_, r = 0, s = 0;
+            if (!pointwise) {
+                const int tap = kh_ / a.cin_g;
+                c = kh_ - tap * a.cin_g;
+                r = tap / a.kw;
+                s = tap - r * a.kw;
+            }
+#pragma unroll
+            for (int i = 0; i < LB; ++i) {
+                rb[i][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const int hi = hi0[i] + r, wi = wi0[i] + s;
+                if (hok && pok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+                    rb[i][h] = *reinterpret_cast<const f32x4*>(a.x + (xbase[i] + (long)hi * a.W + wi) * a.ldx + cbase + c);
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < LA; ++i)
+            if (r0 + 64 * i < TCH) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(sA + p * PLANE_A + (r0 + 64 * i) * S6_ROWB + kq * 16) = ra[i][p];
+            }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            uint4 p0, p1, p2;
+            s6_split8(rb[i][0], rb[i][1], p0, p1, p2);
+            char* dst = sB + (r0 + 64 * i) * S6_ROWB + kq * 16;
+            *reinterpret_cast<uint4*>(dst) = p0;
+            *reinterpret_cast<uint4*>(dst + PLANE_B) = p1;
+            *reinterpret_cast<uint4*>(dst + 2 * PLANE_B) = p2;
+        }
+    };
+
+    f32x4 acc[TCHW][4];
+#pragma unroll
+    for (int i = 0; i < TCHW; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (a.K + SBK - 1) / SBK;
+    fetch(0);
+    for (int ci = 0; ci < nchunks; ++ci) {
+        stash();
+        __syncthreads();
+        if (ci + 1 < nchunks) fetch((ci + 1) * SBK);
+        const char* fa = sA + (wc * TCHW * 16 + l15) * S6_ROWB + kg * 16;
+        const char* fb = sB + (wp_ * 64 + l15) * S6_ROWB + kg * 16;
+        bf16x8 bq[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[j][p] = *reinterpret_cast<const bf16x8*>(fb + j * 16 * S6_ROWB + p * PLANE_B);
+#pragma unroll
+        for (int i = 0; i < TCHW; ++i) {
+            bf16x8 aq[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) aq[p] = *reinterpret_cast<const bf16x8*>(fa + i * 16 * S6_ROWB + p * PLANE_A);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 c = acc[i][j];
+                // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[2], bq[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[0], bq[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[1], bq[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[1], bq[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[0], bq[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[0], bq[j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane = pixel l15 of pixel tile j, accumulator = channels 16 i + 4 kg .. + 3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long m = px0 + wp_ * 64 + j * 16 + l15;
+        if (m >= a.M) continue;
+        float* yrow = a.y + m * a.ldy + a.cout_off + g * a.cout_g;
+        const float* rrow = a.res ? a.res + m * a.ldr + a.res_off + g * a.cout_g : nullptr;
+#pragma unroll
+        for (int i = 0; i < TCHW; ++i) {
+            const int n = ch0 + (wc * TCHW + i) * 16 + 4 * kg;
+            if (n >= a.cout_g) continue;
+            f32x4 v = acc[i][j];
+            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + g * a.cout_g + n);
+            if (a.act_pre) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = vip_act_strict(v[e], a.act_pre);
+            }
+            if (rrow) v += *reinterpret_cast<const f32x4*>(rrow + n);
+            if (a.act_post) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = vip_act_strict(v[e], a.act_post);
+            }
+            *reinterpret_cast<f32x4*>(yrow + n) = v;
+        }
+    }
+}
+
+template <int TCHW>
+int launch_sconv6(const SConv6Args& aa, hipStream_t s) {
+    constexpr int TCH = 32 * TCHW, TPX = 128;
+    const SConvArgs& a = aa.c;
+    const long gx = (a.M + TPX - 1) / TPX;
+    const int gy = (a.cout_g + TCH - 1) / TCH;
+    if (gx > 2147483647L || gy > 65535 || a.groups > 65535) {
+        vip_set_error("vip_conv2d_nhwc_s32x: grid too large (%ld x %d x %d)", gx, gy, a.groups);
+        return VIP_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((sconv6_kernel<TCHW>), dim3((unsigned)gx, gy, a.groups), dim3(256), 0, s, aa);
+    return vip_launch_status("vip_conv2d_nhwc_s32x");
+}
+
 }  // namespace
 
-extern "C" int vip_conv2d_nhwc_s32(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                                   const vip_conv_desc* d, void* stream) {
-    VIP_REQUIRE(x && w && y && d, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_s32: null pointer");
+static int sconv_fill(const char* who, const float* x, const void* w, const float* bias, const float* residual, float* y,
+                      const vip_conv_desc* d, int ldw, SConvArgs& a) {
+    VIP_REQUIRE(x && w && y && d, VIP_ERR_BAD_ARG, "%s: null pointer", who);
     VIP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 && d->sh > 0 && d->sw > 0 &&
                     d->pt >= 0 && d->pl >= 0 && d->Ho > 0 && d->Wo > 0 && d->groups > 0,
-                VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_s32: non-positive dimension");
-    VIP_REQUIRE(d->Cin % d->groups == 0 && d->Cout % d->groups == 0, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_s32: channels not divisible by groups");
-    VIP_REQUIRE((unsigned)d->act_pre <= 4u && (unsigned)d->act_post <= 4u, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_s32: bad activation code");
+                VIP_ERR_BAD_ARG, "%s: non-positive dimension", who);
+    VIP_REQUIRE(d->Cin % d->groups == 0 && d->Cout % d->groups == 0, VIP_ERR_BAD_ARG, "%s: channels not divisible by groups", who);
+    VIP_REQUIRE((unsigned)d->act_pre <= 4u && (unsigned)d->act_post <= 4u, VIP_ERR_BAD_ARG, "%s: bad activation code", who);
     const int cin_g = d->Cin / d->groups, cout_g = d->Cout / d->groups;
-    VIP_REQUIRE(cin_g % 4 == 0 && cout_g % 4 == 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->ldw % 4 == 0 && d->cin_off % 4 == 0 &&
+    VIP_REQUIRE(cin_g % 4 == 0 && cout_g % 4 == 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0 && ldw % 4 == 0 && d->cin_off % 4 == 0 &&
                     d->cout_off % 4 == 0 && d->ldr % 4 == 0 && d->res_off % 4 == 0,
-                VIP_ERR_ALIGNMENT, "vip_conv2d_nhwc_s32: channel counts, strides and offsets must be multiples of 4 floats");
-    VIP_REQUIRE(d->ldx >= d->cin_off + d->Cin && d->ldy >= d->cout_off + d->Cout && d->ldw >= d->kh * d->kw * cin_g, VIP_ERR_BAD_ARG,
-                "vip_conv2d_nhwc_s32: a stride is smaller than the channels it spans");
-    VIP_REQUIRE(!residual || d->ldr >= d->res_off + d->Cout, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_s32: residual stride too small");
+                VIP_ERR_ALIGNMENT, "%s: channel counts, strides and offsets must be multiples of 4 floats", who);
+    VIP_REQUIRE(d->ldx >= d->cin_off + d->Cin && d->ldy >= d->cout_off + d->Cout && ldw >= d->kh * d->kw * cin_g, VIP_ERR_BAD_ARG,
+                "%s: a stride is smaller than the channels it spans", who);
+    VIP_REQUIRE(!residual || d->ldr >= d->res_off + d->Cout, VIP_ERR_BAD_ARG, "%s: residual stride too small", who);
     // the output must be what the padding implies at most (a caller may ask for fewer rows / columns, never more taps than exist)
     VIP_REQUIRE((long)(d->Ho - 1) * d->sh - d->pt < d->H && (long)(d->Wo - 1) * d->sw - d->pl < d->W, VIP_ERR_BAD_ARG,
-                "vip_conv2d_nhwc_s32: output size reaches past the input");
-    SConvArgs a;
-    a.x = x; a.w = w; a.bias = bias; a.res = residual; a.y = y;
+                "%s: output size reaches past the input", who);
+    a.x = x; a.w = (const float*)w; a.bias = bias; a.res = residual; a.y = y;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
     a.kh = d->kh; a.kw = d->kw; a.sh = d->sh; a.sw = d->sw; a.pt = d->pt; a.pl = d->pl;
     a.cin_g = cin_g; a.cout_g = cout_g; a.groups = d->groups;
-    a.ldx = d->ldx; a.cin_off = d->cin_off; a.ldy = d->ldy; a.cout_off = d->cout_off; a.ldr = d->ldr; a.res_off = d->res_off; a.ldw = d->ldw;
+    a.ldx = d->ldx; a.cin_off = d->cin_off; a.ldy = d->ldy; a.cout_off = d->cout_off; a.ldr = d->ldr; a.res_off = d->res_off; a.ldw = ldw;
     a.act_pre = d->act_pre; a.act_post = d->act_post;
     const long M = (long)d->B * d->Ho * d->Wo;
-    VIP_REQUIRE(M < (1L << 31), VIP_ERR_UNSUPPORTED, "vip_conv2d_nhwc_s32: more than 2^31 output pixels");
+    VIP_REQUIRE(M < (1L << 31), VIP_ERR_UNSUPPORTED, "%s: more than 2^31 output pixels", who);
     a.M = (int)M;
     a.K = d->kh * d->kw * cin_g;
+    return VIP_OK;
+}
+
+extern "C" int vip_conv2d_nhwc_s32(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                                   const vip_conv_desc* d, void* stream) {
+    SConvArgs a;
+    const int st = sconv_fill("vip_conv2d_nhwc_s32", x, w, bias, residual, y, d, d ? d->ldw : 0, a);
+    if (st != VIP_OK) return st;
     hipStream_t s = (hipStream_t)stream;
-    if (cout_g > 64) return launch_sconv<2, 2, 2, 2>(a, s);      // 128 channels x 128 pixels
-    if (cout_g > 32) return launch_sconv<2, 2, 1, 2>(a, s);      //  64 channels x 128 pixels
-    return launch_sconv<1, 4, 1, 1>(a, s);                       //  32 channels x 128 pixels
+    if (a.cout_g > 64) return launch_sconv<2, 2, 2, 2>(a, s);      // 128 channels x 128 pixels
+    if (a.cout_g > 32) return launch_sconv<2, 2, 1, 2>(a, s);      //  64 channels x 128 pixels
+    return launch_sconv<1, 4, 1, 1>(a, s);                         //  32 channels x 128 pixels
+}
+
+/* w_planes: the weights split into three bf16 planes [3][Cout][ldwp] (ldwp % 8 == 0, zero padded; plane p starts p * Cout * ldwp
+ * elements in): w = p0 + p1 + p2 exactly.  d->ldw is ignored. */
+extern "C" int vip_conv2d_nhwc_s32x(const float* x, const void* w_planes, int ldwp, const float* bias, const float* residual, float* y,
+                                    const vip_conv_desc* d, void* stream) {
+    SConv6Args aa;
+    VIP_REQUIRE(ldwp > 0 && ldwp % 8 == 0, VIP_ERR_ALIGNMENT, "vip_conv2d_nhwc_s32x: ldwp must be a positive multiple of 8");
+    const int st = sconv_fill("vip_conv2d_nhwc_s32x", x, w_planes, bias, residual, y, d, ldwp, aa.c);
+    if (st != VIP_OK) return st;
+    aa.wp = (const unsigned short*)w_planes;
+    aa.ldwp = ldwp;
+    aa.plane_stride = (long)d->Cout * ldwp;
+    hipStream_t s = (hipStream_t)stream;
+    if (aa.c.cout_g > 64) return launch_sconv6<4>(aa, s);
+    return launch_sconv6<2>(aa, s);
 }

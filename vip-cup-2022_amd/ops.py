@@ -109,6 +109,7 @@ class ConvWeight:
     err: Optional[torch.Tensor] = None   # fp32 [cout, ldw]: (fp32 weight - stored fp16 weight), kept only until calibrate()
     w_lo: Optional[torch.Tensor] = None  # fp16 [cout, ldw]: fp16(W32 - w) for the two-term-weight kernel (see make_conv_weight)
     exact: Optional["ConvWeight"] = None  # calibration only (exact_weights()): [w | fp16(W32 - w)] along K, the uncorrected bias
+    w_bf3: Optional[torch.Tensor] = None  # strict: the fp32 weights as three bf16 planes [3, cout, ldwp] (w = p0 + p1 + p2 exactly)
 
     @property
     def cin(self):
@@ -243,6 +244,28 @@ def diffuse_round_f16(w_rows: torch.Tensor) -> torch.Tensor:
     return q.t().contiguous()
 
 
+def split_bf16x3(w_rows: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[rows, K]`` -> bf16 ``[3, rows, ldwp]`` (ldwp = K rounded up to 8, zero padded) with ``p0 + p1 + p2 == w`` exactly:
+    each plane takes the next 8 significant bits (round-to-nearest of the remainder; both subtractions are exact in fp32).  The weight
+    operand of vip_conv2d_nhwc_s32x."""
+    w = w_rows.detach().to(torch.float32)
+    p0 = w.to(torch.bfloat16)
+    r1 = w - p0.to(torch.float32)
+    p1 = r1.to(torch.bfloat16)
+    r2 = r1 - p1.to(torch.float32)
+    p2 = r2.to(torch.bfloat16)
+    planes = torch.stack([p0, p1, p2], 0)
+    pad = (-w.shape[1]) % 8
+    if pad:
+        planes = torch.cat([planes, planes.new_zeros(3, w.shape[0], pad)], 2)
+    return planes.contiguous()
+
+
+# STRICT GEMM arithmetic: "bf16x3" (default) = three-term bf16 splits, six bf16 MFMAs per block (vip_conv2d_nhwc_s32x); "f32" = the
+# f32-input MFMA (vip_conv2d_nhwc_s32), 2.7x lower matrix rate.  Same results to f32 round-off (tests/test_gpu_strict.py runs both).
+STRICT_GEMM = os.environ.get("VIP_STRICT_GEMM", "bf16x3")
+
+
 HILO_MAX_K = 256     # vip_conv2d_hilo_nhwc_f16: the streaming kernel's K limit
 
 
@@ -281,7 +304,7 @@ def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], gr
                                 "(pad_cin_to / pad_cout_to)")
         w32 = k.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin_g).contiguous()
         return ConvWeight(w=w32.to(device), bias=None if b is None else b.to(device).contiguous(), kh=kh, kw=kw, cin_g=cin_g,
-                          cout=cout, groups=groups, alg_cin_g=alg_cin_g)
+                          cout=cout, groups=groups, alg_cin_g=alg_cin_g, w_bf3=split_bf16x3(w32).to(device))
     # round along (channel, tap): the taps of one input channel see the same mean activation, so their rounding
     # errors are diffused into each other first; the carry then runs on across channels
     hilo = hilo and hilo_eligible(kh, kw, cin_g * groups, groups)
@@ -418,13 +441,16 @@ def _conv2d_s32(x, cw: ConvWeight, stride, pad, act, act_post, residual, out, ci
     if _PROF is not None:
         M = B * Ho * Wo
         kk = cw.kh * cw.kw * cw.alg_cin_g
-        tok = _PROF.start("sconv_kernel", 2.0 * M * cw.cout * kk,
+        tok = _PROF.start("sconv6_kernel" if (STRICT_GEMM == "bf16x3" and cw.w_bf3 is not None) else "sconv_kernel", 2.0 * M * cw.cout * kk,
                           4.0 * (B * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1) + cw.w.numel()),
                           f"M={M} N={cw.cout} K={cw.kh * cw.kw * cw.cin_g} k{cw.kh} s{sh} g{cw.groups}")
-    st = _abi.lib().vip_conv2d_nhwc_s32(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), C.byref(d), _stream())
+    if STRICT_GEMM == "bf16x3" and cw.w_bf3 is not None:
+        st = _abi.lib().vip_conv2d_nhwc_s32x(_p(x), _p(cw.w_bf3), cw.w_bf3.shape[2], _p(cw.bias), _p(residual), _p(out), C.byref(d), _stream())
+    else:
+        st = _abi.lib().vip_conv2d_nhwc_s32(_p(x), _p(cw.w), _p(cw.bias), _p(residual), _p(out), C.byref(d), _stream())
     if tok is not None:
         _PROF.stop(tok)
-    _abi.check(st, "vip_conv2d_nhwc_s32")
+    _abi.check(st, "vip_conv2d_nhwc_s32[x]")
     return out
 
 
