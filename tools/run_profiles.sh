@@ -9,14 +9,14 @@ cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 mkdir -p $OUT
-ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-resident-leg"
+ARGS="bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-resident-leg --no-strict-leg --no-batch-sweep --distinct-batches 4"
 export VIP_BIAS_CALIBRATION=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/streams -- python3 $ARGS > $OUT/bench_streams.json 2> $OUT/bench_streams.err
 cp $(find $OUT/streams -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_streams.csv
 export VIP_STREAMS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -- python3 $ARGS > $OUT/bench_serial.json 2> $OUT/bench_serial.err
 cp $(find $OUT/serial -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_serial.csv
-PMC_ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-resident-leg"
+PMC_ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-resident-leg --no-strict-leg --no-batch-sweep --distinct-batches 2"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $PMC_ARGS > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $PMC_ARGS > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/hbm_traffic_pmc.json > $OUT/pmc_traffic.log 2>&1
