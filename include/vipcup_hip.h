@@ -168,6 +168,22 @@ int vip_dwconv2d_nhwc_f16(const void* x, const float* w, const float* bias, void
                           int B, int H, int W, int C, int k, int stride, int pt, int pl,
                           int Ho, int Wo, int act, void* stream);
 
+/* Depthwise Conv2D that also leaves the sums a following squeeze-excite pool needs (the `DepthwiseConv2D -> activation ->
+ * se_module` run of kecam efficientnet_v2.py:85-97 and `conv = [dw3x3, gelu, SE, ...]` of gcvit/layers/feature.py:46-70,93-96):
+ * every workgroup adds up the activated fp32 outputs of its tiles and writes one row of partial sums,
+ *   partials [B][parts][C] f32,  parts = vip_dwconv2d_pool_parts(...)  (0: shape not handled - use the plain call),
+ * in a fixed order (no atomics: bit-reproducible).  vip_se_gate_pooled_f16 finishes the mean from them instead of reading
+ * the whole map again. */
+int vip_dwconv2d_pool_parts(int B, int H, int W, int C, int k, int stride, int Ho, int Wo);
+int vip_dwconv2d_pool_nhwc_f16(const void* x, const float* w, const float* bias, void* y, float* partials, int parts,
+                               int B, int H, int W, int C, int k, int stride, int pt, int pl, int Ho, int Wo, int act,
+                               void* stream);
+/* vip_se_gate_f16 whose pool arrives as partial sums: mean[b,c] = sum_g partials[b][g][c] / HW (fp32), then the same two
+ * matrix-vector products and output forms. */
+int vip_se_gate_pooled_f16(const float* partials, int parts, const void* w1, const float* b1, const void* w2,
+                           const float* b2, void* gate, int B, int HW, int C, int Cr, int ldw1, int Cout, int ldw2,
+                           int act1, int act2, int split, void* stream);
+
 /* LayerNormalization over the last axis (rows x C), fp32 statistics.
  * Replaces tf.keras.layers.LayerNormalization (gcvit/layers/block.py:28,39; tfimm/layers/factory.py:37-45).
  * gamma/beta f32 [C]. */

@@ -146,6 +146,18 @@ def dwconv2d(x, w_khwc, bias, k, stride=1, pad=(0, 0, 0, 0), act=None):
     return _r(R.act(R.dwconv2d(x, w_khwc.float()[..., None], bias, stride, pad), _an(act)), "dw")
 
 
+def dwconv2d_se(x, w_khwc, bias, k, stride, pad, act, fc1, fc2, act1, act2="sigmoid", split=True):
+    # the pooling form sums the UNROUNDED fp32 outputs of the depthwise kernel (stride 1, small gate); the fallback pools the stored map
+    raw = R.act(R.dwconv2d(x, w_khwc.float()[..., None], bias, stride, pad), _an(act))
+    h = _r(raw, "dw")
+    small = x.shape[-1] * fc1.cout + fc1.cout * fc2.cout <= 256 * 1024
+    if stride == 1 and small and k in (3, 5, 7):
+        pooled = raw.reshape(raw.shape[0], -1, raw.shape[-1]).mean(1)
+        g = _split(dense(dense(pooled, fc1, act=act1, tag=None), fc2, act=act2, tag=None))
+        return h, (g if split else g[:, 0])
+    return h, se_gate(h, fc1, fc2, act1, act2, split)
+
+
 def mbconv_expand_dw(x, cw, w_khwc, dw_bias, k, stride, pad, act=None):
     return dwconv2d(conv2d(x, cw, act=act), w_khwc, dw_bias, k, stride, pad, act=act)
 
@@ -259,7 +271,7 @@ def patched(round_act=False):
     global ROUND_ACT
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops
-    names = ["conv2d", "dense", "dense_split", "gap_ln_dense_f32", "head_prob", "mbconv_expand_dw", "mlp", "se_gate", "dwconv2d", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
+    names = ["conv2d", "dense", "dense_split", "gap_ln_dense_f32", "head_prob", "mbconv_expand_dw", "mlp", "se_gate", "dwconv2d", "dwconv2d_se", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
              "scale_add_act", "mul", "radix_combine", "window_attention", "mhsa", "vit_tokens", "to_device_nhwc8"]
     saved = {n: getattr(ops, n) for n in names}
     old = ROUND_ACT

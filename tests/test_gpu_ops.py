@@ -371,6 +371,55 @@ def test_dwconv(k, s, C, H, report):
     check(report, f"dwconv k{k} s{s} C{C}", got, ref)
 
 
+# depthwise conv + squeeze-excite gate with the pool's partial sums left by the depthwise kernel: ensemble block shapes (EfficientNet
+# B4 / V2-T MBConv, GCViT FeatExtract), maps with one partly idle tile group per image (7x7: 8 tiles of 16 slots), several groups per
+# image, channel counts that leave idle chunk lanes (cb = 12 / 16 against C8 = 18, 30), a stride-2 case and a wide gate (fallbacks)
+@pytest.mark.parametrize("k,s,C,H,W,B,Cr,act", [(3, 1, 64, 56, 56, 3, 16, "gelu"), (3, 1, 144, 7, 7, 5, 8, "silu"),
+                                                 (5, 1, 240, 13, 12, 4, 16, "silu"), (3, 1, 96, 25, 25, 2, 24, "silu"),
+                                                 (5, 1, 672, 12, 12, 3, 32, "silu"), (3, 1, 8, 9, 31, 2, 8, "relu"),
+                                                 (7, 1, 48, 10, 10, 2, 8, None), (3, 2, 72, 15, 15, 2, 8, "silu"),
+                                                 (3, 1, 1152, 6, 6, 2, 288, "silu")])
+def test_dwconv_se_pool(k, s, C, H, W, B, Cr, act, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(k * 100 + C + H)
+    x = h(torch.randn(B, H, W, C, generator=g) + 0.2)
+    w = torch.randn(k, k, C, 1, generator=g) / k
+    b = torch.randn(C, generator=g) * 0.1
+    w1 = h(torch.randn(C, Cr, generator=g) / math.sqrt(C) * 3)
+    b1 = torch.randn(Cr, generator=g) * 0.1
+    w2 = h(torch.randn(Cr, C, generator=g) / math.sqrt(Cr) * 2)
+    b2 = torch.randn(C, generator=g) * 0.1
+    p = k // 2
+    pad = (p, p, p, p)
+    y32 = R.act(R.dwconv2d(x, w, b, s, pad), act)                                   # fp32 map
+    ref_gate = R.act(R.dense(R.act(R.dense(y32.mean(dim=(1, 2)), w1, b1), "silu"), w2, b2), "sigmoid")
+    fc1, fc2 = ops.make_dense_weight(w1, b1), ops.make_dense_weight(w2, b2)
+    wd, bd = w[..., 0].contiguous().cuda(), b.cuda()
+    hh, gate = ops.dwconv2d_se(dev(x), wd, bd, k, s, pad, act, fc1, fc2, "silu", "sigmoid")
+    plain_h = ops.dwconv2d(dev(x), wd, bd, k, s, pad, act=act)
+    plain_gate = ops.se_gate(plain_h, fc1, fc2, "silu", "sigmoid")
+    torch.cuda.synchronize()
+    assert torch.equal(hh, plain_h)                                                  # the map itself is the same kernel arithmetic
+    gsum = gate[:, 0].float() + gate[:, 1].float()
+    small = C * Cr + Cr * C <= 256 * 1024
+    from vipcup_amd import _abi
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    # the fallbacks (stride 2, wide gate, maps whose image-aligned tile groups would idle > 15 % of the lanes) pool the fp16-rounded map
+    pooled_form = small and _abi.lib().vip_dwconv2d_pool_parts(B, H, W, C, k, s, Ho, Wo) > 0
+    if (k, C, H) == (3, 64, 56):
+        assert pooled_form
+    report(f"[ops] dwconv_se k{k} s{s} C{C} {H}x{W}: {'pooling form' if pooled_form else 'two plain launches'}")
+    check(report, f"dwconv_se k{k} s{s} C{C} {H}x{W} B{B} gate vs fp32", gsum, ref_gate, tol=2e-5 if pooled_form else 1e-4)
+    # against the two plain launches: those pool the fp16-ROUNDED map, the pooling form the fp32 outputs - they differ by the rounding
+    # noise of the mean, far below a gate's own fp16 ulp
+    d = (gsum.cpu() - (plain_gate[:, 0].float() + plain_gate[:, 1].float()).cpu()).abs().max().item()
+    report(f"[ops] dwconv_se k{k} s{s} C{C} {H}x{W}: max |gate - gate(two launches)| = {d:.2e}")
+    assert d <= 2e-4
+    again_h, again_gate = ops.dwconv2d_se(dev(x), wd, bd, k, s, pad, act, fc1, fc2, "silu", "sigmoid")
+    torch.cuda.synchronize()
+    assert torch.equal(again_gate, gate) and torch.equal(again_h, hh)                # fixed summation order: bit-reproducible
+
+
 # the matrix-core depthwise kernel (k 7 / 5, stride 1, C % 16 == 0): tile tails in both axes, maps smaller than a tile, several
 # tiles per image and several images per band, asymmetric padding (TF SAME on even sizes is symmetric here; VALID = no padding),
 # every activation epilogue; the filter is fp32 at the boundary and the kernel carries it as hi + lo fp16 - checked to 1e-3 of |y|max

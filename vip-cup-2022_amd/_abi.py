@@ -49,6 +49,9 @@ SIGNATURES = {
     "vip_gemm_split_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 6 + [_vp]),
     "vip_gemm_split2_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 5 + [_vp]),
     "vip_dwconv2d_nhwc_f16": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
+    "vip_dwconv2d_pool_parts": (_i, [_i] * 8),
+    "vip_dwconv2d_pool_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "vip_se_gate_pooled_f16": (_i, [_vp, _i] + [_vp] * 5 + [_i] * 10 + [_vp]),
     "vip_layernorm_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "vip_pool2d_nhwc_f16": (_i, [_vp, _vp] + [_i] * 13 + [_vp]),
     "vip_global_avgpool_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

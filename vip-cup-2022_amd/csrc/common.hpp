@@ -42,8 +42,10 @@ static inline int vip_launch_status(const char* what) {
 }
 
 // stride-1 depthwise fast path (dwconv.hip); returns 1 when the shape is not handled there
+// partials != NULL: the pooling form (per-workgroup partial sums of the outputs, `parts` rows per image = vip_dwconv_tiled_parts)
 int vip_dwconv_tiled(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
-                     int pt, int pl, int Ho, int Wo, int act, hipStream_t s);
+                     int pt, int pl, int Ho, int Wo, int act, hipStream_t s, float* partials = nullptr, int parts = 0);
+int vip_dwconv_tiled_parts(int B, int H, int W, int C, int k, int Ho, int Wo);
 // stride-1 7x7 / 5x5 depthwise on the matrix cores (dwconv_mfma.hip); returns 1 when the shape is not handled there
 int vip_dwconv_mfma(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                     int pt, int pl, int Ho, int Wo, int act, hipStream_t s);

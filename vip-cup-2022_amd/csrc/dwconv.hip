@@ -15,9 +15,9 @@ static int VIP_DW_BLOCKS_PER_CU = 8;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 
-template <int T, int TW, int ACT>
+template <int T, int TW, int ACT, bool POOL>
 __device__ __forceinline__ void dw_store(f32x2 (&acc)[T][TW][4], const float (&bv)[8], f16* __restrict__ y, int b, int oy0,
-                                         int ox0, int Ho, int Wo, int C, int c0) {
+                                         int ox0, int Ho, int Wo, int C, int c0, f32x2 (&ps)[4]) {
 #pragma unroll
     for (int oy = 0; oy < T; ++oy) {
         const int gy = oy0 + oy;
@@ -32,18 +32,23 @@ __device__ __forceinline__ void dw_store(f32x2 (&acc)[T][TW][4], const float (&b
                 const f32x2 v = vip_act2<ACT>(acc[oy][ox][e] + (f32x2){bv[2 * e], bv[2 * e + 1]});
                 o.e[2 * e] = (f16)v.x;
                 o.e[2 * e + 1] = (f16)v.y;
+                if constexpr (POOL) ps[e] += v;        // the activated fp32 values, before the fp16 rounding of the store
             }
             *reinterpret_cast<uint4*>(y + (((long)b * Ho + gy) * Wo + gx) * C + c0) = o.u;
         }
     }
 }
 
-template <int K, int T, int TW, bool WHOLE>
+// POOL: the kernel also leaves per-workgroup partial sums of its (activated, fp32) outputs for the squeeze-excite pool that follows
+// a depthwise convolution in MBConv / GCViT FeatExtract blocks (efficientnet_v2.py:85-97, gcvit feature.py:46-70), so that the gate
+// kernel does not read the whole map again: tile groups are then image-aligned (`gpi` groups per image, the last one partly idle) and
+// group g of image b writes partials[(b * gpi + g) * C + c] - a fixed summation order, no atomics: bit-reproducible.
+template <int K, int T, int TW, bool WHOLE, bool POOL>
 __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ bias, f16* __restrict__ y,
                                                              int B, int H, int W, int C, int pt, int pl, int Ho,
                                                              int Wo, int act, int cb_chunks, int tiles_x, int tiles_y,
-                                                             long n_tiles, long x_bytes) {
+                                                             long n_tiles, long x_bytes, float* __restrict__ partials, int gpi) {
     constexpr int P = T + K - 1;         // input patch rows
     constexpr int PW = TW + K - 1;       // input patch columns (TW output columns per thread)
     extern __shared__ __attribute__((aligned(16))) float wlds[];  // [K*K][cb_chunks*8] fp32
@@ -59,9 +64,16 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
     __syncthreads();
 
     const int tiles_per_block = 256 / cb_chunks;
-    const int lc = threadIdx.x % cb_chunks;                 // chunk inside the block (fastest: coalesced rows)
+    int lc = threadIdx.x % cb_chunks;                       // chunk inside the block (fastest: coalesced rows)
     const int lt = threadIdx.x / cb_chunks;
-    if (lt >= tiles_per_block || lc >= nch) return;
+    const bool lane_ok = lt < tiles_per_block && lc < nch;
+    if constexpr (POOL) {
+        // every lane reaches the barriers of the reduction below: a lane without work runs a tile below the image (all stores and
+        // pooled sums skipped) on a channel chunk that exists
+        if (lc >= nch) lc = nch - 1;
+    } else {
+        if (!lane_ok) return;
+    }
     const int c0 = (c8_0 + lc) * 8;
     const float* wl = wlds + lc * 8;
     // buffer descriptor over the whole input: out-of-image taps use an out-of-range offset and read as zero in
@@ -72,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
     // b, b+8, ... share an XCD and its L2, so each XCD gets one CONTIGUOUS band of tile groups - vertically adjacent
     // tiles re-read K-1 of their T+K-1 input rows, and with a plain grid stride those neighbours sit on other XCDs and
     // every XCD pulls the halo rows over the fabric again (PMC: 2.7x the algorithmic read bytes).
-    const long n_groups = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    const long n_groups = POOL ? (long)B * gpi : (n_tiles + tiles_per_block - 1) / tiles_per_block;
     long g_lo = 0, g_hi = n_groups, g_step = gridDim.x, g_first = blockIdx.x;
     if (gridDim.x >= 8) {
         const int xcd = blockIdx.x & 7;
@@ -83,11 +95,20 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
         g_first = g_lo + (blockIdx.x >> 3);
     }
     for (long grp = g_first; grp < g_hi; grp += g_step) {
-    const long tile = grp * tiles_per_block + lt;
-    if (tile >= n_tiles) break;
-    const int tx = (int)(tile % tiles_x);
-    const int ty = (int)((tile / tiles_x) % tiles_y);
-    const int b = (int)(tile / ((long)tiles_x * tiles_y));
+    int tx, ty, b;
+    if constexpr (POOL) {
+        b = (int)(grp / gpi);
+        const int ti = (int)(grp - (long)b * gpi) * tiles_per_block + lt;
+        const bool work = lane_ok && ti < tiles_x * tiles_y;
+        tx = work ? ti % tiles_x : 0;
+        ty = work ? ti / tiles_x : tiles_y;                  // first output row Ho or beyond: nothing stored, nothing pooled
+    } else {
+        const long tile = grp * tiles_per_block + lt;
+        if (tile >= n_tiles) break;
+        tx = (int)(tile % tiles_x);
+        ty = (int)((tile / tiles_x) % tiles_y);
+        b = (int)(tile / ((long)tiles_x * tiles_y));
+    }
     const int oy0 = ty * T, ox0 = tx * TW;
 
     f32x2 acc[T][TW][4];
@@ -176,19 +197,37 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
         bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
         bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
     }
+    f32x2 ps[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     switch (act) {   // one straight-line, packed-math epilogue per activation
-        case VIP_ACT_RELU: dw_store<T, TW, VIP_ACT_RELU>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
-        case VIP_ACT_SILU: dw_store<T, TW, VIP_ACT_SILU>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
-        case VIP_ACT_GELU: dw_store<T, TW, VIP_ACT_GELU>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
-        case VIP_ACT_SIGMOID: dw_store<T, TW, VIP_ACT_SIGMOID>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
-        default: dw_store<T, TW, VIP_ACT_NONE>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0); break;
+        case VIP_ACT_RELU: dw_store<T, TW, VIP_ACT_RELU, POOL>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0, ps); break;
+        case VIP_ACT_SILU: dw_store<T, TW, VIP_ACT_SILU, POOL>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0, ps); break;
+        case VIP_ACT_GELU: dw_store<T, TW, VIP_ACT_GELU, POOL>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0, ps); break;
+        case VIP_ACT_SIGMOID: dw_store<T, TW, VIP_ACT_SIGMOID, POOL>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0, ps); break;
+        default: dw_store<T, TW, VIP_ACT_NONE, POOL>(acc, bv, y, b, oy0, ox0, Ho, Wo, C, c0, ps); break;
+    }
+    if constexpr (POOL) {
+        // tiles of the group -> one row of partial sums: [tile][channel] through LDS, then one thread per channel adds the tiles
+        // in index order
+        float* red = wlds + K * K * cb_chunks * 8;           // [tiles_per_block][cb_chunks * 8]
+        __syncthreads();                                     // the previous group's readers are done
+        if (lane_ok) {
+            float* r = red + lt * (cb_chunks * 8) + lc * 8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<f32x2*>(r + 2 * e) = ps[e];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nch * 8) {
+            float sum = 0.f;
+            for (int t = 0; t < tiles_per_block; ++t) sum += red[t * (cb_chunks * 8) + threadIdx.x];
+            partials[grp * C + c8_0 * 8 + threadIdx.x] = sum;
+        }
     }
     }   // tile loop
 }
 
 template <int K, int T, int TW, bool WHOLE>
 int launch_tile(const f16* x, const float* w, const float* bias, f16* y, int B, int H, int W, int C, int pt, int pl,
-                int Ho, int Wo, int act, hipStream_t s) {
+                int Ho, int Wo, int act, hipStream_t s, float* partials = nullptr, int parts = 0) {
     const int C8 = C / 8;
     // channel chunks per block: a divisor-friendly width <= 16 chunks (128 channels) that wastes few lanes
     int cb = C8 < 16 ? C8 : 16;
@@ -197,20 +236,46 @@ int launch_tile(const f16* x, const float* w, const float* bias, f16* y, int B, 
     const long n_tiles = (long)B * tiles_x * tiles_y;
     const int tiles_per_block = 256 / cb;
     const int gyc = (C8 + cb - 1) / cb;
-    long gx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    const int gpi = (tiles_x * tiles_y + tiles_per_block - 1) / tiles_per_block;       // image-aligned tile groups (pooling form)
+    long gx = partials ? (long)B * gpi : (n_tiles + tiles_per_block - 1) / tiles_per_block;
     const long gx_cap = (256L * VIP_DW_BLOCKS_PER_CU + gyc - 1) / gyc;     // ~resident blocks of the whole chip
     if (gx > gx_cap) gx = gx_cap;
     const size_t smem = (size_t)K * K * cb * 8 * sizeof(float);
-    hipLaunchKernelGGL((dwconv_tile_kernel<K, T, TW, WHOLE>), dim3((unsigned)gx, (unsigned)gyc), dim3(256), smem, s, x, w, bias, y, B,
-                       H, W, C, pt, pl, Ho, Wo, act, cb, tiles_x, tiles_y, n_tiles, 2L * B * H * W * C);
+    if (partials) {
+        if (parts != gpi) {
+            vip_set_error("vip_dwconv2d_pool_nhwc_f16: partials sized for %d rows per image, the kernel writes %d", parts, gpi);
+            return VIP_ERR_BAD_ARG;
+        }
+        hipLaunchKernelGGL((dwconv_tile_kernel<K, T, TW, WHOLE, true>), dim3((unsigned)gx, (unsigned)gyc), dim3(256),
+                           smem + (size_t)tiles_per_block * cb * 8 * sizeof(float), s, x, w, bias, y, B, H, W, C, pt, pl, Ho, Wo, act,
+                           cb, tiles_x, tiles_y, n_tiles, 2L * B * H * W * C, partials, gpi);
+        return vip_launch_status("vip_dwconv2d_pool_nhwc_f16(tile)");
+    }
+    hipLaunchKernelGGL((dwconv_tile_kernel<K, T, TW, WHOLE, false>), dim3((unsigned)gx, (unsigned)gyc), dim3(256), smem, s, x, w, bias,
+                       y, B, H, W, C, pt, pl, Ho, Wo, act, cb, tiles_x, tiles_y, n_tiles, 2L * B * H * W * C, (float*)nullptr, 0);
     return vip_launch_status("vip_dwconv2d_nhwc_f16(tile)");
+}
+
+// rows of partial sums per image the pooling form writes for this shape (the launcher's own tiling)
+template <int T, int TW>
+int tile_parts(int Ho, int Wo, int C) {
+    const int C8 = C / 8;
+    int cb = C8 < 16 ? C8 : 16;
+    if (C8 % 12 == 0 && C8 % 16 != 0) cb = 12;
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + T - 1) / T;
+    const int tiles_per_block = 256 / cb;
+    const int gpi = (tiles_x * tiles_y + tiles_per_block - 1) / tiles_per_block;
+    // image-aligned groups idle the tail of each image's last group: below ~85 % lane use the depthwise kernel loses more than the
+    // gate kernel saves (7x7 maps: 8 tiles in 16 slots; measured on EfficientNetV2-T, +0.2 ms per 256 images) - plain calls there
+    if (tiles_x * tiles_y * 100 < gpi * tiles_per_block * 85) return 0;
+    return gpi;
 }
 
 }  // namespace
 
 // stride-1 fast path; returns 1 if the shape is not handled here
 int vip_dwconv_tiled(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
-                     int pt, int pl, int Ho, int Wo, int act, hipStream_t s) {
+                     int pt, int pl, int Ho, int Wo, int act, hipStream_t s, float* partials, int parts) {
     const f16* xi = (const f16*)x;
     const float* wi = w;
     f16* yo = (f16*)y;
@@ -219,7 +284,7 @@ int vip_dwconv_tiled(const void* x, const float* w, const float* bias, void* y, 
     // tile widths chosen so that accumulators + one fp32 patch row stay well under 256 VGPRs (no scratch)
     // register tiles (rows x cols per thread) picked by measurement on the ensemble's layer shapes (tools/bench_dw.py):
     // smaller tiles -> fewer VGPRs -> more resident waves, which beats the extra halo loads for k = 3 / 5
-#define VIP_GO(KK, TT, WW, WH) return launch_tile<KK, TT, WW, WH>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s)
+#define VIP_GO(KK, TT, WW, WH) return launch_tile<KK, TT, WW, WH>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s, partials, parts)
     // measured on the ensemble's layer shapes (tools/bench_dw.py): 3x3 wants the whole 4x6 patch in flight (+15-25 %
     // over row-at-a-time); 5x5 / 7x7 whole-patch variants spill, and their rows carry enough FMAs to cover a load
     if (k == 3) VIP_GO(3, 2, 4, true);
@@ -227,4 +292,14 @@ int vip_dwconv_tiled(const void* x, const float* w, const float* bias, void* y, 
     if (k == 7) VIP_GO(7, 2, 4, false);
 #undef VIP_GO
     return 1;
+}
+
+// partial-sum rows per image of the pooling form (same register tiles as above), 0 if the shape is not handled by the tile kernel
+int vip_dwconv_tiled_parts(int B, int H, int W, int C, int k, int Ho, int Wo) {
+    const long gx = ((long)B * ((Wo + 1) / 2) * ((Ho + 1) / 2) + 15) / 16;
+    if (gx >= (1L << 31) || 2L * B * H * W * C >= 0xFFFFFFF0L || C % 8 != 0) return 0;
+    if (k == 3) return tile_parts<2, 4>(Ho, Wo, C);
+    if (k == 5) return tile_parts<2, 2>(Ho, Wo, C);
+    if (k == 7) return tile_parts<2, 4>(Ho, Wo, C);
+    return 0;
 }

@@ -392,6 +392,28 @@ extern "C" int vip_dwconv2d_nhwc_f16(const void* x, const float* w, const float*
     return vip_launch_status("vip_dwconv2d_nhwc_f16");
 }
 
+extern "C" int vip_dwconv2d_pool_parts(int B, int H, int W, int C, int k, int stride, int Ho, int Wo) {
+    if (stride != 1 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return 0;
+    return vip_dwconv_tiled_parts(B, H, W, C, k, Ho, Wo);
+}
+
+extern "C" int vip_dwconv2d_pool_nhwc_f16(const void* x, const float* w, const float* bias, void* y, float* partials, int parts,
+                                          int B, int H, int W, int C, int k, int stride, int pt, int pl, int Ho, int Wo, int act,
+                                          void* stream) {
+    VIP_REQUIRE(x && w && y && partials, VIP_ERR_BAD_ARG, "vip_dwconv2d_pool_nhwc_f16: null pointer");
+    VIP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && pt >= 0 && pl >= 0 && (unsigned)act <= 4u,
+                VIP_ERR_BAD_ARG, "vip_dwconv2d_pool_nhwc_f16: bad argument");
+    VIP_REQUIRE(C % 8 == 0, VIP_ERR_ALIGNMENT, "vip_dwconv2d_pool_nhwc_f16: C must be a multiple of 8");
+    VIP_REQUIRE(stride == 1 && parts > 0 && parts == vip_dwconv_tiled_parts(B, H, W, C, k, Ho, Wo), VIP_ERR_UNSUPPORTED,
+                "vip_dwconv2d_pool_nhwc_f16: k=%d stride=%d parts=%d - ask vip_dwconv2d_pool_parts first", k, stride, parts);
+    const int st = vip_dwconv_tiled(x, w, bias, y, B, H, W, C, k, pt, pl, Ho, Wo, act, (hipStream_t)stream, partials, parts);
+    if (st == 1) {
+        vip_set_error("vip_dwconv2d_pool_nhwc_f16: shape not handled by the tile kernel");
+        return VIP_ERR_UNSUPPORTED;
+    }
+    return st;
+}
+
 // ---------------------------------------------------------------------------------------------
 // classifier head: global average pool + dense, fp32 out.  One block per image.
 // ---------------------------------------------------------------------------------------------

@@ -24,6 +24,8 @@ struct SeArgs {
     f16* gate;
     int HW, C, ldx, Cr, ldw1, Co, ldw2, ldg;
     int act1, act2, split;
+    const float* part;   // pooled form: [B][parts][C] fp32 partial sums of x over pixels (vip_dwconv2d_pool_nhwc_f16), x unused
+    int parts;
 };
 
 constexpr int SE_THREADS = 512;
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(SE_THREADS) void se_gate_kernel(SeArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C8 = a.C >> 3;
     const int cw = C8 < SE_THREADS ? C8 : SE_THREADS;    // channel-chunk lanes
-    const int G = SE_THREADS / cw;                       // pixel groups
+    const int G = a.part ? 1 : SE_THREADS / cw;          // pixel groups (pooled form: the sums arrive as one row)
     float* part = sm;                                    // [G][C]
     float* mean = sm + G * a.C;                          // [C]
     float* hid = mean + a.C;                             // [Cr]
@@ -41,7 +43,14 @@ __global__ __launch_bounds__(SE_THREADS) void se_gate_kernel(SeArgs a) {
 
     // ---- 1. pool: thread = (channel chunk cl (+ k*cw), pixel group pg); 16-byte loads, fp32 sums
     const int cl = tid % cw, pg = tid / cw;
-    if (pg < G) {
+    if (a.part) {
+        const float* pb = a.part + (long)blockIdx.x * a.parts * a.C;
+        for (int c = tid; c < a.C; c += SE_THREADS) {
+            float s = 0.f;
+            for (int g = 0; g < a.parts; ++g) s += pb[(long)g * a.C + c];
+            part[c] = s;                                     // G = 1 row of the reduction below
+        }
+    } else if (pg < G) {
         for (int c8 = cl; c8 < C8; c8 += cw) {
             float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int p = pg;
@@ -137,6 +146,28 @@ extern "C" int vip_se_gate_f16(const void* x, const void* w1, const float* b1, c
     a.x = (const f16*)x; a.w1 = (const f16*)w1; a.b1 = b1; a.w2 = (const f16*)w2; a.b2 = b2; a.gate = (f16*)gate;
     a.HW = HW; a.C = C; a.ldx = ldx; a.Cr = Cr; a.ldw1 = ldw1; a.Co = Cout; a.ldw2 = ldw2; a.ldg = split ? 2 * Cout : Cout;
     a.act1 = act1; a.act2 = act2; a.split = split ? 1 : 0;
+    a.part = nullptr; a.parts = 0;
     hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(SE_THREADS), smem, (hipStream_t)stream, a);
     return vip_launch_status("vip_se_gate_f16");
+}
+
+extern "C" int vip_se_gate_pooled_f16(const float* partials, int parts, const void* w1, const float* b1, const void* w2,
+                                      const float* b2, void* gate, int B, int HW, int C, int Cr, int ldw1, int Cout, int ldw2,
+                                      int act1, int act2, int split, void* stream) {
+    VIP_REQUIRE(partials && w1 && w2 && gate, VIP_ERR_BAD_ARG, "vip_se_gate_pooled_f16: null pointer");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && Cr > 0 && Cout > 0 && parts > 0, VIP_ERR_BAD_ARG,
+                "vip_se_gate_pooled_f16: non-positive dimension");
+    VIP_REQUIRE((unsigned)act1 <= 4u && (unsigned)act2 <= 4u, VIP_ERR_BAD_ARG, "vip_se_gate_pooled_f16: unknown activation code");
+    VIP_REQUIRE(C % 8 == 0 && Cr % 8 == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0, VIP_ERR_ALIGNMENT,
+                "vip_se_gate_pooled_f16: C, Cr and the leading dimensions must be multiples of 8 halfs");
+    VIP_REQUIRE(ldw1 >= C && ldw2 >= Cr, VIP_ERR_BAD_ARG, "vip_se_gate_pooled_f16: leading dimension too small");
+    const size_t smem = ((size_t)C + C + Cr) * sizeof(float);
+    VIP_REQUIRE(smem <= 64 * 1024, VIP_ERR_UNSUPPORTED, "vip_se_gate_pooled_f16: C=%d too wide", C);
+    SeArgs a;
+    a.x = nullptr; a.w1 = (const f16*)w1; a.b1 = b1; a.w2 = (const f16*)w2; a.b2 = b2; a.gate = (f16*)gate;
+    a.HW = HW; a.C = C; a.ldx = C; a.Cr = Cr; a.ldw1 = ldw1; a.Co = Cout; a.ldw2 = ldw2; a.ldg = split ? 2 * Cout : Cout;
+    a.act1 = act1; a.act2 = act2; a.split = split ? 1 : 0;
+    a.part = partials; a.parts = parts;
+    hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(SE_THREADS), smem, (hipStream_t)stream, a);
+    return vip_launch_status("vip_se_gate_pooled_f16");
 }

@@ -84,8 +84,7 @@ class _ConvBranch:
 
     def __call__(self, x):
         """returns x + branch(x)"""
-        y = ops.dwconv2d(x, self.dw, None, 3, 1, PAD1, act="gelu")
-        s = ops.se_gate(y, self.fc0, self.fc2, "gelu", "sigmoid")
+        y, s = ops.dwconv2d_se(x, self.dw, None, 3, 1, PAD1, "gelu", self.fc0, self.fc2, "gelu", "sigmoid")
         return ops.conv2d(y, self.pw, residual=x, gate=s)    # y * s folded into the 1x1 conv's activation load
 
 

@@ -14,6 +14,7 @@ Load-time folding (all exact in fp32, then cast to fp16 once):
   * ECA's Conv1D over channels as a banded [C,C] matrix for the GEMM kernel (common_layers.py:335-353).
 """
 import math
+import os
 from typing import Dict
 
 import torch
@@ -320,11 +321,16 @@ class EfficientNet(_Base):
                     y = ops.conv2d(y, blk["out"], stride=s, pad=pad, act=act, residual=inp if blk["shortcut"] else None)
             else:
                 pad = self._pad(y.shape[1:3], k, s)
-                if blk["exp"] is not None:                           # expand 1x1 + depthwise: one launch where the C ABI takes the shape
-                    h = ops.mbconv_expand_dw(y, blk["exp"], blk["dw"][0], blk["dw"][1], k, s, pad, act=act)
+                if blk["se"] is not None and os.environ.get("VIP_MBCONV_FUSED", "0") != "1":
+                    # depthwise conv that leaves the squeeze-excite pool's partial sums: the gate kernel does not read h again
+                    e = ops.conv2d(y, blk["exp"], act=act) if blk["exp"] is not None else y
+                    h, a = ops.dwconv2d_se(e, blk["dw"][0], blk["dw"][1], k, s, pad, act, blk["se"][0], blk["se"][1], act, "sigmoid")
                 else:
-                    h = ops.dwconv2d(y, blk["dw"][0], blk["dw"][1], k, s, pad, act=act)
-                a = ops.se_gate(h, blk["se"][0], blk["se"][1], act, "sigmoid") if blk["se"] is not None else None
+                    if blk["exp"] is not None:                       # expand 1x1 + depthwise: one launch where the C ABI takes the shape
+                        h = ops.mbconv_expand_dw(y, blk["exp"], blk["dw"][0], blk["dw"][1], k, s, pad, act=act)
+                    else:
+                        h = ops.dwconv2d(y, blk["dw"][0], blk["dw"][1], k, s, pad, act=act)
+                    a = ops.se_gate(h, blk["se"][0], blk["se"][1], act, "sigmoid") if blk["se"] is not None else None
                 y = ops.conv2d(h, blk["out"], residual=inp if blk["shortcut"] else None, gate=a)   # h * se folded in
             last_of_stage = i + 1 == len(self.blocks) or self.blocks[i + 1]["stage"] != blk["stage"]
             if collect is not None and last_of_stage:

@@ -594,6 +594,42 @@ def dwconv2d(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stri
     return out
 
 
+_DW_SE_FUSED = os.environ.get("VIP_DW_SE_POOL", "1") != "0"
+
+
+def dwconv2d_se(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride, pad, act, fc1: ConvWeight, fc2: ConvWeight,
+                act1, act2="sigmoid", split: bool = True):
+    """``h = act(dwconv(x))`` and the squeeze-excite gate of ``h`` (``se_gate(h, fc1, fc2, act1, act2, split)``) - the
+    DepthwiseConv2D -> activation -> se_module run of an MBConv block (kecam efficientnet_v2.py:85-97) and of GCViT's FeatExtract /
+    ReduceSize (gcvit/layers/feature.py:46-70,93-96).  Returns ``(h, gate)``.  Where the C ABI takes the shape (stride 1, the tile
+    kernel; gate matrices small enough for the one-launch gate) the depthwise kernel leaves per-workgroup partial sums of its fp32
+    outputs and the gate kernel finishes the mean from those instead of reading ``h`` again (``vip_dwconv2d_pool_nhwc_f16`` +
+    ``vip_se_gate_pooled_f16``; ``VIP_DW_SE_POOL=0``: always the two plain calls)."""
+    B, H, W, Cc = x.shape
+    pt, pb, pl, pr = pad
+    Ho = (H + pt + pb - k) // stride + 1
+    Wo = (W + pl + pr - k) // stride + 1
+    fused = (_DW_SE_FUSED and not _UNFUSED and not _CALIB and not _EXACT and x.dtype == torch.float16 and stride == 1
+             and fc1.cin == Cc and Cc * fc1.cout + fc1.cout * fc2.cout <= 256 * 1024
+             and w_khwc.dtype == torch.float32 and w_khwc.is_contiguous() and w_khwc.shape == (k, k, Cc))
+    parts = _abi.lib().vip_dwconv2d_pool_parts(B, H, W, Cc, k, stride, Ho, Wo) if fused else 0
+    if parts <= 0:
+        h = dwconv2d(x, w_khwc, bias, k, stride, pad, act=act)
+        return h, se_gate(h, fc1, fc2, act1, act2, split=split)
+    _chk16(x, "dwconv2d_se.x")
+    assert fc1.groups == 1 and fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1 and fc2.cin == fc1.cout
+    h = torch.empty((B, Ho, Wo, Cc), dtype=torch.float16, device=x.device)
+    partials = torch.empty((B, parts, Cc), dtype=torch.float32, device=x.device)
+    st = _abi.lib().vip_dwconv2d_pool_nhwc_f16(_p(x), _p(w_khwc), _p(bias), _p(h), _p(partials), parts, B, H, W, Cc, k, stride, pt, pl,
+                                               Ho, Wo, _act(act), _stream())
+    _abi.check(st, "vip_dwconv2d_pool_nhwc_f16")
+    gate = torch.empty((B, 2, fc2.cout) if split else (B, fc2.cout), dtype=torch.float16, device=x.device)
+    st = _abi.lib().vip_se_gate_pooled_f16(_p(partials), parts, _p(fc1.w), _p(fc1.bias), _p(fc2.w), _p(fc2.bias), _p(gate), B, Ho * Wo,
+                                           Cc, fc1.cout, fc1.ldw, fc2.cout, fc2.ldw, _act(act1), _act(act2), int(split), _stream())
+    _abi.check(st, "vip_se_gate_pooled_f16")
+    return h, gate
+
+
 def mbconv_expand_dw(x, cw: ConvWeight, w_khwc: torch.Tensor, dw_bias: Optional[torch.Tensor], k: int, stride: int, pad, act=None):
     """``act(dwconv(act(conv1x1(x, cw)), w_khwc) + dw_bias)`` - the expand convolution and the depthwise convolution of an MBConv
     block - as ``conv2d`` then ``dwconv2d``, or with ``VIP_MBCONV_FUSED=1`` in ONE launch where the C ABI takes the shape (the
