@@ -246,6 +246,24 @@ int vip_radix_combine2_f16(const void* x, const void* scale, int scale_planes, v
                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GCViT attention half of a block in ONE launch - the fused form of the north-star path:
+ *   y = x + proj( window_attention( qkv( LayerNorm(x) ) ) )       gcvit/layers/block.py:58-79, attention.py:52-83
+ * for the level-0 configuration C = 64, 2 heads of 32, 7 x 7 windows (vip_gcvit_attn_block_supported; other levels run
+ * vip_layernorm_f16 -> vip_gemm_bias_act_f16 -> vip_window_attn_fwd_f16 -> vip_gemm_bias_act_f16).
+ *   x, y [B][Hp][Wp][C] f16, Hp and Wp multiples of 7, y must not alias x ; q_global [B][49][C] f16 or NULL ;
+ *   wqkv [nq*C][ldwq] f16 (nq = 3: q, k, v rows; nq = 2 with q_global: k, v), bqkv [nq*C] f32 or NULL ;
+ *   wproj [C][ldwp] f16 (layer scale folded in by the caller), bproj [C] f32 or NULL ; ln_gamma, ln_beta [C] f32 ;
+ *   table [(2 ws - 1)^2][heads] f32 ; scale = head_dim^-0.5.
+ * Same roundings as the four launches (LayerNorm output, q / k / v, attention output and y are rounded to fp16 at the same
+ * points); the proj sum runs over the head channels in another order, so y agrees to fp32 summation order, not bitwise.
+ * ------------------------------------------------------------------------------------------ */
+int vip_gcvit_attn_block_supported(int C, int heads, int ws);
+int vip_gcvit_attn_block_f16(const void* x, const void* q_global, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                             const void* wqkv, int ldwq, const float* bqkv, const void* wproj, int ldwp, const float* bproj,
+                             const float* table, void* y, int B, int Hp, int Wp, int C, int heads, int ws, float scale,
+                             void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * GCViT window attention core (gcvit/layers/attention.py:52-83, window.py:3-15):
  *   out = softmax( (q*scale) k^T + rel_bias ) v     per (image, window, head)
  * qkv        [B, Hp, Wp, nq*C] f16, feature-map layout (NOT window-partitioned): the window

@@ -246,6 +246,11 @@ def window_attention(qkv, q_global, table, heads, ws, scale):
     return _r(R.window_reverse(o.permute(0, 2, 1, 3).reshape(B_, ws * ws, C), ws, Hp, Wp, C), "attn")
 
 
+def gcvit_attn_block(x, q_global, ln, qkv, proj, table, heads, ws, scale):
+    y = dense(layernorm(x, ln[0], ln[1], float(ln[2])), qkv)
+    return dense(window_attention(y, q_global, table, heads, ws, scale), proj, residual=x)
+
+
 def mhsa(qkv, heads, scale):
     B, N, D3 = qkv.shape
     D = D3 // 3
@@ -272,7 +277,7 @@ def patched(round_act=False):
     import vipcup_amd  # noqa: F401
     from vipcup_amd import ops
     names = ["conv2d", "dense", "dense_split", "gap_ln_dense_f32", "head_prob", "mbconv_expand_dw", "mlp", "se_gate", "dwconv2d", "dwconv2d_se", "layernorm", "pool2d", "global_avgpool", "gap_dense_f32", "cls_dense_f32",
-             "scale_add_act", "mul", "radix_combine", "window_attention", "mhsa", "vit_tokens", "to_device_nhwc8"]
+             "scale_add_act", "mul", "radix_combine", "window_attention", "gcvit_attn_block", "mhsa", "vit_tokens", "to_device_nhwc8"]
     saved = {n: getattr(ops, n) for n in names}
     old = ROUND_ACT
     ROUND_ACT = round_act

@@ -35,7 +35,15 @@ def _victims():
     with ops.precision("strict"):
         cws = ops.make_conv_weight(torch.randn(1, 1, 256, 256, generator=g) / 16, torch.zeros(256))
     xs32 = torch.randn(64, 14, 14, 256, generator=g).cuda()
+    xb = r(16, 56, 56, 64)
+    lnb = (torch.ones(64).cuda(), torch.zeros(64).cuda(), 1e-5)
+    cq3 = ops.make_dense_weight(torch.randn(64, 192, generator=g) / 8, torch.zeros(192))
+    cq2 = ops.make_dense_weight(torch.randn(64, 128, generator=g) / 8, torch.zeros(128))
+    cpj = ops.make_dense_weight(torch.randn(64, 64, generator=g) / 8, torch.zeros(64))
+    qgb = r(16, 49, 64)
     return {
+        "gcvit_attn_block (fused)": lambda: ops.gcvit_attn_block(xb, None, lnb, cq3, cpj, tab7, 2, 7, 32 ** -0.5),
+        "gcvit_attn_block global q": lambda: ops.gcvit_attn_block(xb, qgb, lnb, cq2, cpj, tab7, 2, 7, 32 ** -0.5),
         "window_attn ws14": lambda: ops.window_attention(qkv14, None, tab14, 8, 14, 32 ** -0.5),
         "window_attn ws14 global": lambda: ops.window_attention(qkv14g, qg14, tab14, 8, 14, 32 ** -0.5),
         "window_attn ws7": lambda: ops.window_attention(qkv7, None, tab7, 2, 7, 32 ** -0.5),

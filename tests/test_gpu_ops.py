@@ -719,6 +719,56 @@ def test_window_attention_pipelined(B, heads, nW, global_q, report):
     assert torch.equal(got, plain), "the pipelined kernel changes the schedule, not the arithmetic"
 
 
+@pytest.mark.parametrize("B,nW,global_q", [(2, 1, False), (3, 2, True), (5, 3, False), (1, 8, True), (9, 4, False)])
+def test_gcvit_attn_block_fused(B, nW, global_q, report, monkeypatch):
+    """vip_gcvit_attn_block_f16 (LayerNorm -> qkv -> window attention -> proj + residual in one launch, level-0 configuration)
+    against block.py:58-79 restated in fp32 and against the four launches it replaces: window counts that are not a multiple of the
+    4 waves of a workgroup, more windows than the persistent grid walks in one pass (B = 9, 16 windows each), local and global query."""
+    ops = _ops()
+    ws, heads, C, hd = 7, 2, 64, 32
+    Hp = Wp = ws * nW
+    g = torch.Generator().manual_seed(B * 100 + nW * 10 + int(global_q))
+    nq = 2 if global_q else 3
+    x = h(torch.randn(B, Hp, Wp, C, generator=g) * 1.5 + 0.2)
+    gam, bet = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.1
+    wq, bq = h(torch.randn(C, nq * C, generator=g) / math.sqrt(C)), torch.randn(nq * C, generator=g) * 0.1
+    wp, bp = h(torch.randn(C, C, generator=g) / math.sqrt(C)), torch.randn(C, generator=g) * 0.1
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5
+    qg = h(torch.randn(B, ws, ws, C, generator=g)) if global_q else None
+    # fp32 restatement
+    xn = R.layernorm(x, gam, bet, 1e-5)
+    qkv = R.dense(xn, wq, bq)
+    win = R.window_partition(qkv, ws).reshape(-1, ws * ws, nq, heads, hd).permute(2, 0, 3, 1, 4)
+    B_ = win.shape[1]
+    if global_q:
+        k, v = win[0], win[1]
+        q = torch.repeat_interleave(qg, B_ // B, dim=0).reshape(B_, ws * ws, heads, hd).permute(0, 2, 1, 3)
+    else:
+        q, k, v = win[0], win[1], win[2]
+    o = gcvit_ref.window_attention_core(q, k, v, table, ws, hd ** -0.5)
+    att = R.window_reverse(o.permute(0, 2, 1, 3).reshape(B_, ws * ws, C), ws, Hp, Wp, C)
+    ref = x + R.dense(att, wp, bp)
+    cq, cp = ops.make_dense_weight(wq, bq), ops.make_dense_weight(wp, bp)
+    ln = (gam.cuda(), bet.cuda(), 1e-5)
+    xd, gd, td = dev(x), None if qg is None else dev(qg).reshape(B, ws * ws, C), table.cuda()
+    from vipcup_amd import _abi
+    assert _abi.lib().vip_gcvit_attn_block_supported(C, heads, ws) == 1 and _abi.lib().vip_gcvit_attn_block_supported(128, 4, 7) == 0
+    got = ops.gcvit_attn_block(xd, gd, ln, cq, cp, td, heads, ws, hd ** -0.5)
+    torch.cuda.synchronize()
+    check(report, f"gcvit_attn_block fused B{B} nW{nW} global={global_q}", got, ref, tol=3e-3)
+    monkeypatch.setattr(ops, "_GCVIT_BLOCK_FUSED", False)
+    four = ops.gcvit_attn_block(xd, gd, ln, cq, cp, td, heads, ws, hd ** -0.5)
+    torch.cuda.synchronize()
+    monkeypatch.setattr(ops, "_GCVIT_BLOCK_FUSED", True)
+    check(report, f"gcvit_attn_block four launches B{B} nW{nW} global={global_q}", four, ref, tol=3e-3)
+    d = (got.float() - four.float()).abs().max().item()
+    report(f"[ops] gcvit_attn_block B{B} nW{nW} global={global_q}: max |fused - four launches| = {d:.2e} (|y| max {ref.abs().max().item():.2f})")
+    assert d <= 2e-3 * ref.abs().max().item()          # the same roundings; the proj sum in another order: an fp16 ulp here and there
+    again = ops.gcvit_attn_block(xd, gd, ln, cq, cp, td, heads, ws, hd ** -0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(got, again)
+
+
 def test_window_attention_softmax_spike(report):
     """One key dominating one query (large logit) must not overflow and must pick that key's value."""
     ops = _ops()

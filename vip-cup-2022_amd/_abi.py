@@ -58,6 +58,8 @@ SIGNATURES = {
     "vip_global_avgpool_split_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vip_gap_dense_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vip_experiments_built": (_i, []),
+    "vip_gcvit_attn_block_supported": (_i, [_i, _i, _i]),
+    "vip_gcvit_attn_block_f16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp] + [_i] * 6 + [_f, _vp]),
     "vip_mbconv_expand_dw_supported": (_i, [_i, _i, _i, _i]),
     "vip_mbconv_expand_dw_f16": (_i, [_vp] * 7 + [_i] * 14 + [_vp]),
     "vip_head_prob_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),

@@ -134,10 +134,9 @@ class _Block:
     def __call__(self, x, q_global):
         C = x.shape[-1]
         hd = C // self.heads
-        qkv = ops.dense(self.n1(x), self.qkv)
-        att = ops.window_attention(qkv, q_global if self.global_query else None, self.table, self.heads, self.ws,
-                                   hd ** -0.5)
-        x = ops.dense(att, self.proj, residual=x)            # x + attn   (gamma1 = 1, block.py:54-56,79)
+        # x + attn(norm1(x))  (gamma1 folded into proj, block.py:54-56,79): one launch at level 0, four elsewhere
+        x = ops.gcvit_attn_block(x, q_global if self.global_query else None, (self.n1.g, self.n1.b, LN_EPS), self.qkv, self.proj,
+                                 self.table, self.heads, self.ws, hd ** -0.5)
         return ops.mlp(x, self.fc1, self.fc2, act="gelu", residual=x, ln=(self.n2.g, self.n2.b, LN_EPS))   # x + mlp(norm2(x))  (:80)
 
 

@@ -860,6 +860,39 @@ def window_attention(qkv, q_global, bias_table, heads: int, ws: int, scale: floa
     return out
 
 
+_GCVIT_BLOCK_FUSED = os.environ.get("VIP_GCVIT_BLOCK_FUSED", "1") != "0"
+
+
+def gcvit_attn_block(x, q_global, ln, qkv: ConvWeight, proj: ConvWeight, bias_table, heads: int, ws: int, scale: float):
+    """``x + proj(window_attention(qkv(LayerNorm(x))))`` - the attention half of a GCViT block (gcvit/layers/block.py:58-79) on the
+    feature-map layout ``[B, Hp, Wp, C]``; ``ln = (gamma, beta, eps)``, ``q_global`` ``[B, ws*ws, C]`` or None.  ONE launch
+    (``vip_gcvit_attn_block_f16``: x in, y out, nothing in between leaves the CU) where the C ABI takes the configuration - level 0:
+    C = 64, 2 heads, 7 x 7 windows - otherwise LayerNorm, Dense, attention core, Dense + residual as four launches
+    (``VIP_GCVIT_BLOCK_FUSED=0``: always; calibration / exact-weight passes too, they hook the Dense layers)."""
+    B, Hp, Wp, Cc = x.shape
+    nq = 2 if q_global is not None else 3
+    fused = (_GCVIT_BLOCK_FUSED and not _UNFUSED and not _CALIB and not _EXACT and x.dtype == torch.float16 and x.is_contiguous()
+             and _PROF is None and qkv.w_lo is None and proj.w_lo is None and qkv.groups == 1 and proj.groups == 1
+             and qkv.kh == qkv.kw == proj.kh == proj.kw == 1 and qkv.cin == Cc and qkv.cout == nq * Cc and proj.cin == Cc
+             and proj.cout == Cc and Hp % ws == 0 and Wp % ws == 0
+             and _abi.lib().vip_gcvit_attn_block_supported(Cc, heads, ws))
+    if not fused:
+        y = dense(layernorm(x, ln[0], ln[1], float(ln[2])), qkv)
+        att = window_attention(y, q_global, bias_table, heads, ws, scale)
+        return dense(att, proj, residual=x)
+    _chk16(x, "gcvit_attn_block.x")
+    if q_global is not None:
+        _chk16(q_global, "gcvit_attn_block.q_global")
+        assert q_global.numel() == B * ws * ws * Cc
+    assert bias_table.dtype == torch.float32 and bias_table.shape == ((2 * ws - 1) ** 2, heads) and bias_table.is_contiguous()
+    out = torch.empty_like(x)
+    st = _abi.lib().vip_gcvit_attn_block_f16(_p(x), _p(q_global), _p(ln[0]), _p(ln[1]), float(ln[2]), _p(qkv.w), qkv.ldw, _p(qkv.bias),
+                                             _p(proj.w), proj.ldw, _p(proj.bias), _p(bias_table), _p(out), B, Hp, Wp, Cc, heads, ws,
+                                             float(scale), _stream())
+    _abi.check(st, "vip_gcvit_attn_block_f16")
+    return out
+
+
 def mhsa(qkv, heads: int, scale: float):
     """ViT attention core: qkv ``[B,N,3D]`` -> ``[B,N,D]``."""
     s32 = _is32(qkv, "mhsa.qkv")
