@@ -248,8 +248,9 @@ int vip_radix_combine2_f16(const void* x, const void* scale, int scale_planes, v
 /* ------------------------------------------------------------------------------------------
  * GCViT attention half of a block in ONE launch - the fused form of the north-star path:
  *   y = x + proj( window_attention( qkv( LayerNorm(x) ) ) )       gcvit/layers/block.py:58-79, attention.py:52-83
- * for the level-0 configuration C = 64, 2 heads of 32, 7 x 7 windows (vip_gcvit_attn_block_supported; other levels run
- * vip_layernorm_f16 -> vip_gemm_bias_act_f16 -> vip_window_attn_fwd_f16 -> vip_gemm_bias_act_f16).
+ * for the level-0 and level-1 configurations - 7 x 7 windows, C = 64 with 2 heads of 32 or C = 128 with 4
+ * (vip_gcvit_attn_block_supported; other levels run vip_layernorm_f16 -> vip_gemm_bias_act_f16 -> vip_window_attn_fwd_f16 ->
+ * vip_gemm_bias_act_f16).
  *   x, y [B][Hp][Wp][C] f16, Hp and Wp multiples of 7, y must not alias x ; q_global [B][49][C] f16 or NULL ;
  *   wqkv [nq*C][ldwq] f16 (nq = 3: q, k, v rows; nq = 2 with q_global: k, v), bqkv [nq*C] f32 or NULL ;
  *   wproj [C][ldwp] f16 (layer scale folded in by the caller), bproj [C] f32 or NULL ; ln_gamma, ln_beta [C] f32 ;

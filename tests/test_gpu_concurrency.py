@@ -41,7 +41,12 @@ def _victims():
     cq2 = ops.make_dense_weight(torch.randn(64, 128, generator=g) / 8, torch.zeros(128))
     cpj = ops.make_dense_weight(torch.randn(64, 64, generator=g) / 8, torch.zeros(64))
     qgb = r(16, 49, 64)
+    xb1, tab7b = r(16, 28, 28, 128), (torch.randn(13 * 13, 4, generator=g) * 0.5).cuda()
+    lnb1 = (torch.ones(128).cuda(), torch.zeros(128).cuda(), 1e-5)
+    cq31 = ops.make_dense_weight(torch.randn(128, 384, generator=g) / 11, torch.zeros(384))
+    cpj1 = ops.make_dense_weight(torch.randn(128, 128, generator=g) / 11, torch.zeros(128))
     return {
+        "gcvit_attn_block C128": lambda: ops.gcvit_attn_block(xb1, None, lnb1, cq31, cpj1, tab7b, 4, 7, 32 ** -0.5),
         "gcvit_attn_block (fused)": lambda: ops.gcvit_attn_block(xb, None, lnb, cq3, cpj, tab7, 2, 7, 32 ** -0.5),
         "gcvit_attn_block global q": lambda: ops.gcvit_attn_block(xb, qgb, lnb, cq2, cpj, tab7, 2, 7, 32 ** -0.5),
         "window_attn ws14": lambda: ops.window_attention(qkv14, None, tab14, 8, 14, 32 ** -0.5),

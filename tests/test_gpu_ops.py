@@ -719,15 +719,17 @@ def test_window_attention_pipelined(B, heads, nW, global_q, report):
     assert torch.equal(got, plain), "the pipelined kernel changes the schedule, not the arithmetic"
 
 
-@pytest.mark.parametrize("B,nW,global_q", [(2, 1, False), (3, 2, True), (5, 3, False), (1, 8, True), (9, 4, False)])
-def test_gcvit_attn_block_fused(B, nW, global_q, report, monkeypatch):
+@pytest.mark.parametrize("heads", [2, 4])
+@pytest.mark.parametrize("B,nW,global_q", [(2, 1, False), (3, 2, True), (5, 3, False), (1, 8, True), (9, 4, False), (67, 4, True)])
+def test_gcvit_attn_block_fused(B, nW, global_q, heads, report, monkeypatch):
     """vip_gcvit_attn_block_f16 (LayerNorm -> qkv -> window attention -> proj + residual in one launch, level-0 configuration)
-    against block.py:58-79 restated in fp32 and against the four launches it replaces: window counts that are not a multiple of the
-    4 waves of a workgroup, more windows than the persistent grid walks in one pass (B = 9, 16 windows each), local and global query."""
+    against block.py:58-79 restated in fp32 and against the four launches it replaces: both configurations (C = 64 / 2 heads: a wave per
+    window; C = 128 / 4 heads: two waves per window and workgroup barriers), window counts that are not a multiple of the 4 windows of
+    a workgroup pass, more windows than the persistent grid walks in one pass (B = 67, 16 windows each), local and global query."""
     ops = _ops()
-    ws, heads, C, hd = 7, 2, 64, 32
+    ws, C, hd = 7, 32 * heads, 32
     Hp = Wp = ws * nW
-    g = torch.Generator().manual_seed(B * 100 + nW * 10 + int(global_q))
+    g = torch.Generator().manual_seed(B * 100 + nW * 10 + int(global_q) + heads * 1000)
     nq = 2 if global_q else 3
     x = h(torch.randn(B, Hp, Wp, C, generator=g) * 1.5 + 0.2)
     gam, bet = torch.randn(C, generator=g) * 0.2 + 1.0, torch.randn(C, generator=g) * 0.1
@@ -752,17 +754,17 @@ def test_gcvit_attn_block_fused(B, nW, global_q, report, monkeypatch):
     ln = (gam.cuda(), bet.cuda(), 1e-5)
     xd, gd, td = dev(x), None if qg is None else dev(qg).reshape(B, ws * ws, C), table.cuda()
     from vipcup_amd import _abi
-    assert _abi.lib().vip_gcvit_attn_block_supported(C, heads, ws) == 1 and _abi.lib().vip_gcvit_attn_block_supported(128, 4, 7) == 0
+    assert _abi.lib().vip_gcvit_attn_block_supported(C, heads, ws) == 1 and _abi.lib().vip_gcvit_attn_block_supported(256, 8, 14) == 0
     got = ops.gcvit_attn_block(xd, gd, ln, cq, cp, td, heads, ws, hd ** -0.5)
     torch.cuda.synchronize()
-    check(report, f"gcvit_attn_block fused B{B} nW{nW} global={global_q}", got, ref, tol=3e-3)
+    check(report, f"gcvit_attn_block fused C{C} B{B} nW{nW} global={global_q}", got, ref, tol=3e-3)
     monkeypatch.setattr(ops, "_GCVIT_BLOCK_FUSED", False)
     four = ops.gcvit_attn_block(xd, gd, ln, cq, cp, td, heads, ws, hd ** -0.5)
     torch.cuda.synchronize()
     monkeypatch.setattr(ops, "_GCVIT_BLOCK_FUSED", True)
-    check(report, f"gcvit_attn_block four launches B{B} nW{nW} global={global_q}", four, ref, tol=3e-3)
+    check(report, f"gcvit_attn_block four launches C{C} B{B} nW{nW} global={global_q}", four, ref, tol=3e-3)
     d = (got.float() - four.float()).abs().max().item()
-    report(f"[ops] gcvit_attn_block B{B} nW{nW} global={global_q}: max |fused - four launches| = {d:.2e} (|y| max {ref.abs().max().item():.2f})")
+    report(f"[ops] gcvit_attn_block C{C} B{B} nW{nW} global={global_q}: max |fused - four launches| = {d:.2e} (|y| max {ref.abs().max().item():.2f})")
     assert d <= 2e-3 * ref.abs().max().item()          # the same roundings; the proj sum in another order: an fp16 ulp here and there
     again = ops.gcvit_attn_block(xd, gd, ln, cq, cp, td, heads, ws, hd ** -0.5)
     torch.cuda.synchronize()

@@ -866,8 +866,8 @@ _GCVIT_BLOCK_FUSED = os.environ.get("VIP_GCVIT_BLOCK_FUSED", "1") != "0"
 def gcvit_attn_block(x, q_global, ln, qkv: ConvWeight, proj: ConvWeight, bias_table, heads: int, ws: int, scale: float):
     """``x + proj(window_attention(qkv(LayerNorm(x))))`` - the attention half of a GCViT block (gcvit/layers/block.py:58-79) on the
     feature-map layout ``[B, Hp, Wp, C]``; ``ln = (gamma, beta, eps)``, ``q_global`` ``[B, ws*ws, C]`` or None.  ONE launch
-    (``vip_gcvit_attn_block_f16``: x in, y out, nothing in between leaves the CU) where the C ABI takes the configuration - level 0:
-    C = 64, 2 heads, 7 x 7 windows - otherwise LayerNorm, Dense, attention core, Dense + residual as four launches
+    (``vip_gcvit_attn_block_f16``: x in, y out, nothing in between leaves the CU) where the C ABI takes the configuration - levels 0
+    and 1: 7 x 7 windows, C = 64 / 2 heads or C = 128 / 4 heads - otherwise LayerNorm, Dense, attention core, Dense + residual as four launches
     (``VIP_GCVIT_BLOCK_FUSED=0``: always; calibration / exact-weight passes too, they hook the Dense layers)."""
     B, Hp, Wp, Cc = x.shape
     nq = 2 if q_global is not None else 3
