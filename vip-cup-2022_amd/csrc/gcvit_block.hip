@@ -22,6 +22,12 @@
 // 8 waves = 4 windows per workgroup, the K / V image of a window shared by its two waves (workgroup barriers around it; every
 // workgroup walks the same number of window quartets, a wave past the end runs on out-of-range offsets), qkv weights in LDS (108 KB),
 // proj weight fragments straight from global (32 KB, L2-resident: LDS is full).
+// Measured at B = 256 (tools/bench_gcvit_block.py): C = 64: 124 us local / 110 us global query against 301 / 264 us for the four launches;
+// C = 128: 118 / 116 us against 172 / 152 us.  Per window and wave the C = 64 kernel issues 192 MFMAs (3.1 k matrix cycles), ~1 450
+// VALU instructions (128 of them v_exp_f32) and ~200 LDS operations behind 145 s_waitcnt: two waves per SIMD do not cover those waits
+// (VALU + MFMA issue alone would be ~60 us).  Tried and dropped: the next window's rows requested into the dead x^ registers under
+// the last head's attention pass (124 -> 124 us: the x fetch is not what the waves wait for); two waves per window at C = 64 to get
+// under 128 VGPRs and four waves per SIMD (158 us: workgroup barriers and 37 spilled registers cost more than the occupancy buys).
 #include "common.hpp"
 
 namespace {
