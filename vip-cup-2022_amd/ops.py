@@ -872,7 +872,7 @@ def gcvit_attn_block(x, q_global, ln, qkv: ConvWeight, proj: ConvWeight, bias_ta
     B, Hp, Wp, Cc = x.shape
     nq = 2 if q_global is not None else 3
     fused = (_GCVIT_BLOCK_FUSED and not _UNFUSED and not _CALIB and not _EXACT and x.dtype == torch.float16 and x.is_contiguous()
-             and _PROF is None and qkv.w_lo is None and proj.w_lo is None and qkv.groups == 1 and proj.groups == 1
+             and qkv.w_lo is None and proj.w_lo is None and qkv.groups == 1 and proj.groups == 1
              and qkv.kh == qkv.kw == proj.kh == proj.kw == 1 and qkv.cin == Cc and qkv.cout == nq * Cc and proj.cin == Cc
              and proj.cout == Cc and Hp % ws == 0 and Wp % ws == 0
              and _abi.lib().vip_gcvit_attn_block_supported(Cc, heads, ws))
@@ -886,9 +886,17 @@ def gcvit_attn_block(x, q_global, ln, qkv: ConvWeight, proj: ConvWeight, bias_ta
         assert q_global.numel() == B * ws * ws * Cc
     assert bias_table.dtype == torch.float32 and bias_table.shape == ((2 * ws - 1) ** 2, heads) and bias_table.is_contiguous()
     out = torch.empty_like(x)
+    tok = None
+    if _PROF is not None:
+        # the fused form of SURVEY.md section 8(d): per window 2 N C^2 (1 + nq) + 4 N^2 C FLOPs (= 8 N C^2 + 4 N^2 C with q, k, v) and
+        # 4 N C bytes (x in, y out, fp16)
+        nwin, N = B * (Hp // ws) * (Wp // ws), ws * ws
+        tok = _PROF.start("gcvit_attn_block_kernel", nwin * (2.0 * N * Cc * Cc * (1 + nq) + 4.0 * N * N * Cc), nwin * 4.0 * N * Cc)
     st = _abi.lib().vip_gcvit_attn_block_f16(_p(x), _p(q_global), _p(ln[0]), _p(ln[1]), float(ln[2]), _p(qkv.w), qkv.ldw, _p(qkv.bias),
                                              _p(proj.w), proj.ldw, _p(proj.bias), _p(bias_table), _p(out), B, Hp, Wp, Cc, heads, ws,
                                              float(scale), _stream())
+    if tok is not None:
+        _PROF.stop(tok)
     _abi.check(st, "vip_gcvit_attn_block_f16")
     return out
 
