@@ -720,12 +720,14 @@ def test_window_attention_pipelined(B, heads, nW, global_q, report):
 
 
 @pytest.mark.parametrize("heads", [2, 4])
-@pytest.mark.parametrize("B,nW,global_q", [(2, 1, False), (3, 2, True), (5, 3, False), (1, 8, True), (9, 4, False), (67, 4, True)])
+@pytest.mark.parametrize("B,nW,global_q", [(2, 1, False), (3, 2, True), (5, 3, False), (1, 8, True), (9, 4, False), (67, 4, True),
+                                           (33, 8, False)])
 def test_gcvit_attn_block_fused(B, nW, global_q, heads, report, monkeypatch):
     """vip_gcvit_attn_block_f16 (LayerNorm -> qkv -> window attention -> proj + residual in one launch, level-0 configuration)
     against block.py:58-79 restated in fp32 and against the four launches it replaces: both configurations (C = 64 / 2 heads: a wave per
     window; C = 128 / 4 heads: two waves per window and workgroup barriers), window counts that are not a multiple of the 4 windows of
-    a workgroup pass, more windows than the persistent grid walks in one pass (B = 67, 16 windows each), local and global query."""
+    a workgroup pass, more windows than the persistent grid walks in one pass (1 072 windows > 4 x 256 workgroups at C = 128; 2 112 > 4 x 512 at C = 64), local
+    and global query."""
     ops = _ops()
     ws, C, hd = 7, 32 * heads, 32
     Hp = Wp = ws * nW
