@@ -45,7 +45,19 @@ def _victims():
     lnb1 = (torch.ones(128).cuda(), torch.zeros(128).cuda(), 1e-5)
     cq31 = ops.make_dense_weight(torch.randn(128, 384, generator=g) / 11, torch.zeros(384))
     cpj1 = ops.make_dense_weight(torch.randn(128, 128, generator=g) / 11, torch.zeros(128))
+    xb2 = r(24, 14, 14, 256)
+    lnb2 = (torch.ones(256).cuda(), torch.zeros(256).cuda(), 1e-5)
+    cq32 = ops.make_dense_weight(torch.randn(256, 768, generator=g) / 16, torch.zeros(768))
+    cq22 = ops.make_dense_weight(torch.randn(256, 512, generator=g) / 16, torch.zeros(512))
+    cpj2 = ops.make_dense_weight(torch.randn(256, 256, generator=g) / 16, torch.zeros(256))
+    qgb2 = r(24, 196, 256)
+    from vipcup_amd import _abi
+    exp = {}
+    if _abi.lib().vip_experiments_built():          # the opt-in 14 x 14-window fused block (experiments build)
+        exp = {"gcvit_attn_block ws14": lambda: ops.gcvit_attn_block(xb2, None, lnb2, cq32, cpj2, tab14, 8, 14, 32 ** -0.5),
+               "gcvit_attn_block ws14 gq": lambda: ops.gcvit_attn_block(xb2, qgb2, lnb2, cq22, cpj2, tab14, 8, 14, 32 ** -0.5)}
     return {
+        **exp,
         "gcvit_attn_block C128": lambda: ops.gcvit_attn_block(xb1, None, lnb1, cq31, cpj1, tab7b, 4, 7, 32 ** -0.5),
         "gcvit_attn_block (fused)": lambda: ops.gcvit_attn_block(xb, None, lnb, cq3, cpj, tab7, 2, 7, 32 ** -0.5),
         "gcvit_attn_block global q": lambda: ops.gcvit_attn_block(xb, qgb, lnb, cq2, cpj, tab7, 2, 7, 32 ** -0.5),
@@ -60,9 +72,10 @@ def _victims():
     }
 
 
-def test_kernels_are_bit_exact_next_to_a_busy_matrix_pipe(report):
+def test_kernels_are_bit_exact_next_to_a_busy_matrix_pipe(report, monkeypatch):
     import vipcup_amd  # noqa: F401
-    from vipcup_amd import _abi
+    from vipcup_amd import _abi, ops
+    monkeypatch.setattr(ops, "_GCVIT_BLOCK14", True)          # the opt-in ws 14 fused block is a victim too
     lib = _abi.lib()
     sink = torch.zeros((16,), dtype=torch.float32, device="cuda")
     flops = C.c_double(0.0)

@@ -719,7 +719,7 @@ def test_window_attention_pipelined(B, heads, nW, global_q, report):
     assert torch.equal(got, plain), "the pipelined kernel changes the schedule, not the arithmetic"
 
 
-@pytest.mark.parametrize("heads", [2, 4])
+@pytest.mark.parametrize("heads", [2, 4, 8])
 @pytest.mark.parametrize("B,nW,global_q", [(2, 1, False), (3, 2, True), (5, 3, False), (1, 8, True), (9, 4, False), (67, 4, True),
                                            (33, 8, False)])
 def test_gcvit_attn_block_fused(B, nW, global_q, heads, report, monkeypatch):
@@ -729,7 +729,14 @@ def test_gcvit_attn_block_fused(B, nW, global_q, heads, report, monkeypatch):
     a workgroup pass, more windows than the persistent grid walks in one pass (1 072 windows > 4 x 256 workgroups at C = 128; 2 112 > 4 x 512 at C = 64), local
     and global query."""
     ops = _ops()
-    ws, C, hd = 7, 32 * heads, 32
+    ws, C, hd = (14 if heads == 8 else 7), 32 * heads, 32     # 8 heads: the level-2 configuration, one 8-wave workgroup per 196-token window
+    if heads == 8:
+        from vipcup_amd import _abi as _a
+        if not _a.lib().vip_experiments_built():
+            pytest.skip("the 14 x 14-window fused block is an experiments-build kernel (VIP_BUILD_EXPERIMENTS=1 python build.py)")
+        if nW == 8:
+            pytest.skip("64 windows of 196 tokens per image: covered by the smaller cases")
+        nW, B = (nW + 1) // 2, (B if B < 60 else 131 * 2)      # 1 - 2 windows a side; 262 x 4 windows > one pass of the 256 workgroups
     Hp = Wp = ws * nW
     g = torch.Generator().manual_seed(B * 100 + nW * 10 + int(global_q) + heads * 1000)
     nq = 2 if global_q else 3
@@ -756,7 +763,8 @@ def test_gcvit_attn_block_fused(B, nW, global_q, heads, report, monkeypatch):
     ln = (gam.cuda(), bet.cuda(), 1e-5)
     xd, gd, td = dev(x), None if qg is None else dev(qg).reshape(B, ws * ws, C), table.cuda()
     from vipcup_amd import _abi
-    assert _abi.lib().vip_gcvit_attn_block_supported(C, heads, ws) == 1 and _abi.lib().vip_gcvit_attn_block_supported(256, 8, 14) == 0
+    assert _abi.lib().vip_gcvit_attn_block_supported(C, heads, ws) == 1 and _abi.lib().vip_gcvit_attn_block_supported(512, 16, 7) == 0
+    monkeypatch.setattr(ops, "_GCVIT_BLOCK14", True)          # the ws 14 form is opt-in (not faster than the four launches)
     got = ops.gcvit_attn_block(xd, gd, ln, cq, cp, td, heads, ws, hd ** -0.5)
     torch.cuda.synchronize()
     check(report, f"gcvit_attn_block fused C{C} B{B} nW{nW} global={global_q}", got, ref, tol=3e-3)

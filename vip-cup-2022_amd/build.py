@@ -19,7 +19,7 @@ ARCH = "gfx950"
 # Experiments - kernels that measured slower than what they would replace - are only compiled on request:
 #   VIP_BUILD_EXPERIMENTS=1 python vip-cup-2022_amd/build.py --force
 EXPERIMENTS = os.environ.get("VIP_BUILD_EXPERIMENTS", "0") == "1"
-EXPERIMENT_SOURCES = {"dwconv_mfma.hip", "mbconv_fused.hip"}
+EXPERIMENT_SOURCES = {"dwconv_mfma.hip", "mbconv_fused.hip", "gcvit_block14.hip"}
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
             "-Wno-unused-result", "-ffp-contract=fast", f"-DVIP_BUILD_EXPERIMENTS={int(EXPERIMENTS)}"] \
     + os.environ.get("VIP_EXTRA_CXXFLAGS", "").split()

@@ -50,6 +50,11 @@ int vip_dwconv_tiled_parts(int B, int H, int W, int C, int k, int Ho, int Wo);
 int vip_dwconv_mfma(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                     int pt, int pl, int Ho, int Wo, int act, hipStream_t s);
 
+// the 14 x 14-window configuration (C = 256, 8 heads) of vip_gcvit_attn_block_f16 (gcvit_block14.hip); arguments validated by the caller
+int vip_gcvit_attn_block14(const void* x, const void* q_global, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* wqkv,
+                           int ldwq, const float* bqkv, const void* wproj, int ldwp, const float* bproj, const float* table, void* y,
+                           int B, int Hp, int Wp, float scale, hipStream_t s);
+
 // ---- device helpers -------------------------------------------------------------------------
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the fp16 output rounding): 1 rcp + 1 exp2 +
 // 7 FMAs, branch-free.  libm's erff is a two-branch polynomial (~50 VALU instructions when lanes diverge) and

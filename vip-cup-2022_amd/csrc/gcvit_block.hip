@@ -458,7 +458,17 @@ int launch_gcvit_block(const GbArgs& a, bool global_q, hipStream_t s) {
 
 }  // namespace
 
+#if !VIP_BUILD_EXPERIMENTS
+// gcvit_block14.hip (the 14 x 14-window form: correct, not faster than the four launches) is an experiment-build source
+int vip_gcvit_attn_block14(const void*, const void*, const float*, const float*, float, const void*, int, const float*, const void*, int,
+                           const float*, const float*, void*, int, int, int, float, hipStream_t) {
+    vip_set_error("vip_gcvit_attn_block_f16: the 14 x 14-window form is only in the experiments build (VIP_BUILD_EXPERIMENTS=1)");
+    return VIP_ERR_UNSUPPORTED;
+}
+#endif
+
 extern "C" int vip_gcvit_attn_block_supported(int C, int heads, int ws) {
+    if (ws == 14) return VIP_BUILD_EXPERIMENTS && C == 256 && heads == 8;     // gcvit_block14.hip
     return ws == GB_WS && C == 32 * heads && (heads == 2 || heads == 4);
 }
 
@@ -475,7 +485,7 @@ extern "C" int vip_gcvit_attn_block_f16(const void* x, const void* q_global, con
     VIP_REQUIRE(x && ln_gamma && ln_beta && wqkv && wproj && table && y, VIP_ERR_BAD_ARG, "vip_gcvit_attn_block_f16: null pointer");
     VIP_REQUIRE(x != y, VIP_ERR_BAD_ARG, "vip_gcvit_attn_block_f16: y must not alias x");
     VIP_REQUIRE(vip_gcvit_attn_block_supported(C, heads, ws), VIP_ERR_UNSUPPORTED,
-                "vip_gcvit_attn_block_f16: C=%d heads=%d ws=%d (only 64 / 2 / 7 and 128 / 4 / 7)", C, heads, ws);
+                "vip_gcvit_attn_block_f16: C=%d heads=%d ws=%d (only 64 / 2 / 7, 128 / 4 / 7 and 256 / 8 / 14)", C, heads, ws);
     VIP_REQUIRE(B > 0 && Hp > 0 && Wp > 0 && scale > 0.f, VIP_ERR_BAD_ARG, "vip_gcvit_attn_block_f16: non-positive dimension or scale");
     VIP_REQUIRE(Hp % ws == 0 && Wp % ws == 0, VIP_ERR_BAD_ARG, "vip_gcvit_attn_block_f16: feature map %dx%d not a multiple of the window",
                 Hp, Wp);
@@ -483,6 +493,9 @@ extern "C" int vip_gcvit_attn_block_f16(const void* x, const void* q_global, con
                 "vip_gcvit_attn_block_f16: weight row strides must be multiples of 8 halfs and >= C");
     const long bytes = 2L * B * Hp * Wp * C;
     VIP_REQUIRE(bytes < 0xFFFFFFF0L, VIP_ERR_UNSUPPORTED, "vip_gcvit_attn_block_f16: tensor exceeds the 4 GiB buffer-addressing range");
+    if (ws == 14)
+        return vip_gcvit_attn_block14(x, q_global, ln_gamma, ln_beta, ln_eps, wqkv, ldwq, bqkv, wproj, ldwp, bproj, table, y, B, Hp, Wp, scale,
+                                      (hipStream_t)stream);
     GbArgs a;
     a.x = (const f16*)x; a.qg = (const f16*)q_global; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.ln_eps = ln_eps;
     a.wqkv = (const f16*)wqkv; a.bqkv = bqkv; a.wproj = (const f16*)wproj; a.bproj = bproj; a.table = table; a.y = (f16*)y;

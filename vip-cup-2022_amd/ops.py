@@ -861,6 +861,9 @@ def window_attention(qkv, q_global, bias_table, heads: int, ws: int, scale: floa
 
 
 _GCVIT_BLOCK_FUSED = os.environ.get("VIP_GCVIT_BLOCK_FUSED", "1") != "0"
+# the 14 x 14-window form of the fused block (C = 256, 8 heads: csrc/gcvit_block14.hip) is correct and NOT faster than the four launches
+# (116 us either way at B = 256: one 8-wave workgroup per CU, three barriers and a synchronous 51 KB weight stage per head) - opt-in
+_GCVIT_BLOCK14 = os.environ.get("VIP_GCVIT_BLOCK14", "0") == "1"
 
 
 def gcvit_attn_block(x, q_global, ln, qkv: ConvWeight, proj: ConvWeight, bias_table, heads: int, ws: int, scale: float):
@@ -874,7 +877,7 @@ def gcvit_attn_block(x, q_global, ln, qkv: ConvWeight, proj: ConvWeight, bias_ta
     fused = (_GCVIT_BLOCK_FUSED and not _UNFUSED and not _CALIB and not _EXACT and x.dtype == torch.float16 and x.is_contiguous()
              and qkv.w_lo is None and proj.w_lo is None and qkv.groups == 1 and proj.groups == 1
              and qkv.kh == qkv.kw == proj.kh == proj.kw == 1 and qkv.cin == Cc and qkv.cout == nq * Cc and proj.cin == Cc
-             and proj.cout == Cc and Hp % ws == 0 and Wp % ws == 0
+             and proj.cout == Cc and Hp % ws == 0 and Wp % ws == 0 and (ws != 14 or _GCVIT_BLOCK14)
              and _abi.lib().vip_gcvit_attn_block_supported(Cc, heads, ws))
     if not fused:
         y = dense(layernorm(x, ln[0], ln[1], float(ln[2])), qkv)
