@@ -58,7 +58,9 @@ def parse():
     ap.add_argument("--no-strict-leg", action="store_true")
     ap.add_argument("--no-batch-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batches", type=int, default=3, help="timed CPU batches of 128 images (after one discarded)")
+    ap.add_argument("--cpu-batches", type=int, default=1, help="timed CPU batches (after the discarded warm-up images)")
+    ap.add_argument("--cpu-batch", type=int, default=48, help="images per timed CPU batch (SURVEY 8(d) protocol: 128)")
+    ap.add_argument("--cpu-warm", type=int, default=8, help="images of the discarded CPU warm-up batch (SURVEY 8(d) protocol: 128)")
     ap.add_argument("--no-resident-leg", action="store_true")
     return ap.parse_args()
 
@@ -85,12 +87,14 @@ def host_cores() -> int:
     return min(n, int(os.environ.get("VIP_CPU_THREADS", "16")))
 
 
-def cpu_baseline(wl, timed_batches: int):
-    """SURVEY.md section 8(d) protocol with the fp32 CPU oracle (oracle/*: a port - the reference's TF/Keras path cannot run here):
-    the same synthetic JPEGs, batch 128 (the reference's batch, main.py:85), first batch discarded, `timed_batches` >= 3 timed batches,
-    torch threads = every host core this process may use; per batch: Pillow (libjpeg-turbo) decode -> oracle bicubic resize + /255 per
-    member resolution -> every member's oracle forward (the reference re-decodes per member, main.py:67,89 - decode is counted once
-    per member resolution here, in its favour)."""
+def cpu_baseline(wl, timed_batches: int, bs: int = 48, warm: int = 8):
+    """The fp32 CPU oracle (oracle/*: a port - the reference's TF/Keras path cannot run here) on a BOUNDED sample of the same
+    workload: `warm` images discarded (tfimm/utils/profile.py:30-42 discards its first batch), then `timed_batches` batches of `bs`
+    of the same synthetic JPEGs - about 30 s of CPU work at the defaults (SURVEY.md section 8(d)'s full protocol is batch 128, one
+    discarded + three timed batches: `--cpu-batch 128 --cpu-warm 128 --cpu-batches 3`, ~4 minutes).  torch threads = every host
+    core this process may use; per batch: Pillow (libjpeg-turbo) decode -> oracle bicubic resize + /255 per member resolution ->
+    every member's oracle forward (the reference re-decodes per member, main.py:67,89 - decode is counted once per member
+    resolution here, in its favour)."""
     import importlib
     import io
     import numpy as np
@@ -99,12 +103,11 @@ def cpu_baseline(wl, timed_batches: int):
     from vipcup_amd import zoo
     threads = host_cores()
     torch.set_num_threads(threads)
-    bs = 128
-    raws = (wl.jpegs * (bs // len(wl.jpegs) + 1))[:bs]
+    pool = wl.jpegs * (max(bs, warm) // len(wl.jpegs) + 1)
     params = {m: zoo.build_params(m) for m in wl.members}
     refs = {m: importlib.import_module(f"oracle.{zoo.MEMBERS[m].oracle}") for m in wl.members}
 
-    def one_batch():
+    def one_batch(raws):
         pix = [np.asarray(Image.open(io.BytesIO(r)).convert("RGB")) for r in raws]
         inputs = {}
         for m in wl.members:
@@ -115,16 +118,16 @@ def cpu_baseline(wl, timed_batches: int):
             for m in wl.members:
                 refs[m].predict_logits(m, params[m], inputs[zoo.MEMBERS[m].input_hw])
 
-    note(f"cpu_baseline: {threads} threads, batch {bs}, 1 discarded + {timed_batches} timed batches x {len(wl.members)} members")
-    one_batch()                                  # discarded (tfimm/utils/profile.py:30-42)
+    note(f"cpu_baseline: {threads} threads, {warm} images discarded + {timed_batches} timed batch(es) of {bs} x {len(wl.members)} members")
+    one_batch(pool[:warm])                       # discarded
     t0 = time.perf_counter()
     for i in range(timed_batches):
-        one_batch()
+        one_batch(pool[:bs])
         note(f"cpu_baseline: batch {i + 1}/{timed_batches} done, {time.perf_counter() - t0:.0f} s")
     dt = time.perf_counter() - t0
     return {"value": timed_batches * bs / dt, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"{timed_batches} timed batches of {bs} synthetic JPEGs (1 discarded) x {len(wl.members)} members: Pillow decode + "
-                      f"oracle resize + fp32 torch-CPU oracle forward, {threads} threads",
+            "sample": f"{timed_batches} timed batch(es) of {bs} synthetic JPEGs ({warm} images discarded first) x {len(wl.members)} members: "
+                      f"Pillow decode + oracle resize + fp32 torch-CPU oracle forward, {threads} threads",
             "seconds": dt}
 
 
@@ -300,7 +303,7 @@ def main():
         roof = wl.roofline(peaks)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(wl, max(3, a.cpu_batches))
+        cpu = cpu_baseline(wl, max(1, a.cpu_batches), max(1, a.cpu_batch), max(1, a.cpu_warm))
 
     if rank == 0:
         images = a.batch * world * a.steps
