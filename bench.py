@@ -265,8 +265,8 @@ def main():
         dts = timed_steps(ws, dist, k_strict, 1)
         strict = {"images_per_sec": a.batch * world * k_strict / dts, "ms_per_step": dts / k_strict * 1e3, "steps": k_strict,
                   "arithmetic": ("fp32 storage, GEMMs as a three-term bf16 split (6 x v_mfma_f32_16x16x32_bf16 per block, fp32 "
-                                 "accumulate), libm activations" if ops.STRICT_GEMM == "bf16x3" else
-                                 "fp32 storage, v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak), libm activations"),
+                                 "accumulate), fp32 activations" if ops.STRICT_GEMM == "bf16x3" else
+                                 "fp32 storage, v_mfma_f32_32x32x2_f32 (157 TFLOP/s peak), fp32 activations"),
                   "gemm": ops.STRICT_GEMM,
                   "parity": "every member's calibrated logit and logit(ensemble mean) within 1e-3 of the fp32 oracle "
                             "(tests/test_gpu_strict.py)"}

@@ -389,8 +389,9 @@ int vip_ensemble_mean_f32(const float* scores, float* mean, int M, int n, long l
  * fp16 storage floor of each graph (7e-4 ... 8e-3 with the amplifying synthetic heads); these entry points are
  * the mode in which the tolerance is met member by member.  Activations, weights, biases, gates: fp32, NHWC / row-major, every
  * channel count, stride and offset a multiple of 4 floats; strides in vip_conv_desc are in FLOATS.  Contractions run on
- * v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate: 157 TFLOP/s on MI355X, 1/16 of the fp16 rate); activations use libm
- * expf / erff and true divisions.  Each entry point replaces the same reference call sites as its _f16 counterpart:
+ * v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulate: 157 TFLOP/s on MI355X, 1/16 of the fp16 rate); activations are evaluated
+ * in fp32 to 3e-7 absolute (v_exp_f32 / v_rcp_f32, Abramowitz-Stegun 7.1.26 erf), the attention softmax with libm expf and true
+ * divisions.  Each entry point replaces the same reference call sites as its _f16 counterpart:
  *   vip_conv2d_nhwc_s32        Conv2D / Dense (+ folded BN) (+ act) (+ residual): resnet_rs_model.py:64-84, kecam common_layers.py:190-248,
  *                              gcvit/layers/attention.py:25,33, tfimm/layers/transformers.py:192-205 (w [Cout][kh][kw][Cin_g] f32)
  *   vip_dwconv2d_nhwc_s32      DepthwiseConv2D: gcvit/layers/feature.py:93,133, tfimm convnext.py:192-198, kecam efficientnet_v2.py:85

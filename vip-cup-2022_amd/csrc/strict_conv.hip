@@ -19,6 +19,7 @@
 // K order inside a 32-k chunk: lane half h of k-step (c, j) holds k = 8c + 4h + j for BOTH operands (one ds_read_b128 per operand
 // row and 8 k), which is a permutation of the chunk's k - a sum does not care.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -482,6 +483,9 @@ extern "C" int vip_conv2d_nhwc_s32x(const float* x, const void* w_planes, int ld
     aa.ldwp = ldwp;
     aa.plane_stride = (long)d->Cout * ldwp;
     hipStream_t s = (hipStream_t)stream;
-    if (aa.c.cout_g > 64) return launch_sconv6<4>(aa, s);
+    // short K = HBM-bound (fp32 tensors): the 64-channel tile (158 VGPRs, 45 KB: three workgroups per CU instead of two) keeps more
+    // loads in flight; deeper K stays on the 128-channel tile (half the activation re-reads per MFMA)
+    static const int narrow_max_k = getenv("VIP_S6_NARROW_MAXK") ? atoi(getenv("VIP_S6_NARROW_MAXK")) : 192;   // 192.7 -> 184.7 ms of GEMM per strict step
+    if (aa.c.cout_g > 64 && aa.c.K > narrow_max_k) return launch_sconv6<4>(aa, s);
     return launch_sconv6<2>(aa, s);
 }

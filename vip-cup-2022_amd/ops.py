@@ -62,7 +62,7 @@ def _is32(t: torch.Tensor, name: str) -> bool:
 
 # ---- precision mode ------------------------------------------------------------------------------------------------------------
 # "fast":   fp16 storage of activations and weights, fp32 accumulate (the throughput path; member logits at the fp16 storage floor).
-# "strict": fp32 storage, fp32 matrix arithmetic (v_mfma_f32_32x32x2_f32), libm activations - what the reference computes in
+# "strict": fp32 storage, fp32 matrix arithmetic (v_mfma_f32_32x32x2_f32 or three-term bf16 splits), fp32 activations - what the reference computes in
 #           (main.py:107-109, TensorFlow fp32) and the mode in which BASELINE.json's |dz| <= 1e-3 holds for every member.
 # The mode is a property of the WEIGHTS a model was constructed with (``precision("strict")`` around the constructor) and of the
 # activation dtype it is fed: every operator below dispatches on ``x.dtype``.
