@@ -417,6 +417,11 @@ int vip_conv2d_nhwc_s32(const float* x, const float* w, const float* bias, const
  * split inside the kernel.  d->ldw is ignored; everything else as vip_conv2d_nhwc_s32.  The default of the STRICT path. */
 int vip_conv2d_nhwc_s32x(const float* x, const void* w_planes, int ldwp, const float* bias, const float* residual, float* y,
                          const vip_conv_desc* d, void* stream);
+/* The same with TWO bf16 terms per operand (planes 0 and 1 of the same w_planes tensor; three MFMAs per block: b0 c0 + b0 c1 + b1 c0):
+ * 2^-17 of each product is dropped - 64x finer than fp16 storage, not f32 quality; twice the matrix rate of vip_conv2d_nhwc_s32x.
+ * Opt-in (VIP_STRICT_GEMM=bf16x2). */
+int vip_conv2d_nhwc_s32x2(const float* x, const void* w_planes, int ldwp, const float* bias, const float* residual, float* y,
+                          const vip_conv_desc* d, void* stream);
 int vip_dwconv2d_nhwc_s32(const float* x, const float* w, const float* bias, float* y, int B, int H, int W, int C, int k,
                           int stride, int pt, int pl, int Ho, int Wo, int act, void* stream);
 int vip_layernorm_s32(const float* x, const float* gamma, const float* beta, float* y, int rows, int C, float eps, void* stream);

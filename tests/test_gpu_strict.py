@@ -58,10 +58,11 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("gemm", ["bf16x3", "f32"])
+@pytest.mark.parametrize("gemm", ["bf16x3", "f32", "bf16x2"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:9]))
 def test_conv2d_strict(case, gemm, report, monkeypatch):
-    """both STRICT GEMM arithmetics: three-term bf16 splits on six bf16 MFMAs (the default) and the f32-input MFMA"""
+    """the STRICT GEMM arithmetics: three-term bf16 splits on six bf16 MFMAs (the default) and the f32-input MFMA - f32 quality, 2e-5 -
+    and the opt-in two-term split (three MFMAs, 2^-17 of each product dropped: held to 1e-4 of the output scale)"""
     ops = _ops()
     monkeypatch.setattr(ops, "STRICT_GEMM", gemm)
     B, H, W, Cin, Cout, k, s, pad, groups, act, use_res = case
@@ -80,7 +81,7 @@ def test_conv2d_strict(case, gemm, report, monkeypatch):
     got = ops.conv2d(dev(x), cw, stride=s, pad=pad, act=act, residual=None if res is None else dev(res))
     torch.cuda.synchronize()
     assert got.dtype == torch.float32
-    check(report, f"conv2d[{gemm}] {case}", got, ref)
+    check(report, f"conv2d[{gemm}] {case}", got, ref, tol=1e-4 if gemm == "bf16x2" else TOL_OP)
 
 
 def test_conv2d_strict_channel_slices_and_gate(report):
@@ -251,6 +252,25 @@ def test_member_logit_within_north_star(key, report):
     report(f"[strict] {key:22s} {n} images: max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e} logit std {z.std():.2f}")
     assert np.isfinite(zg).all()
     assert dz.max() <= P.TOL_NORTH_STAR
+
+
+@pytest.mark.parametrize("key", ["efficientnet_v1b4", "efficientnet_v2t", "resnest50"])
+def test_member_logit_two_term_gemm(key, report, monkeypatch):
+    """VIP_STRICT_GEMM=bf16x2 (opt-in: twice the matrix rate, +32 % images/s for the strict step): the three members with the largest
+    errors still sit inside the north-star 1e-3 (measured 2.4e-4 ... 3.4e-4 here, 4.5e-4 on the photographs), with a margin of 2-4x
+    instead of the default arithmetic's 20x"""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ops, pipeline
+    monkeypatch.setattr(ops, "STRICT_GEMM", "bf16x2")
+    n = N_IMG
+    raws = [synth_jpeg(i) for i in P.e2e_image_ids(n)]
+    z = P.oracle_logits(key, "e2e", raws)
+    spec, model = P.gpu_member(key, "strict")
+    x = pipeline.decode_jpegs(raws).resized(spec.input_hw, spec.input_hw, dtype=torch.float32)
+    zg = model.logits(x)[:, 0].float().cpu().numpy()
+    dz = np.abs(zg - z)
+    report(f"[strict/bf16x2] {key:22s} {n} images: max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e}")
+    assert np.isfinite(zg).all() and dz.max() <= P.TOL_NORTH_STAR
 
 
 def test_ensemble_logit_within_north_star(report):

@@ -85,6 +85,7 @@ SIGNATURES = {
     # STRICT precision path (fp32 storage, fp32 arithmetic): csrc/strict_conv.hip, csrc/strict_ops.hip
     "vip_conv2d_nhwc_s32": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
     "vip_conv2d_nhwc_s32x": (_i, [_vp, _vp, _i, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
+    "vip_conv2d_nhwc_s32x2": (_i, [_vp, _vp, _i, _vp, _vp, _vp, C.POINTER(ConvDesc), _vp]),
     "vip_dwconv2d_nhwc_s32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp]),
     "vip_layernorm_s32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "vip_pool2d_nhwc_s32": (_i, [_vp, _vp] + [_i] * 13 + [_vp]),

@@ -250,14 +250,14 @@ __device__ __forceinline__ void s6_split8(const f32x4& lo, const f32x4& hi, uint
     p2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }
 
-template <int TCHW>                  // 16-channel tiles per wave: 4 (block = 128 channels) or 2 (64 channels)
-__global__ __launch_bounds__(256, 2) void sconv6_kernel(SConv6Args aa) {
+template <int TCHW, int NP = 3>      // 16-channel tiles per wave: 4 (block = 128 channels) or 2 (64 channels); NP bf16 terms per operand
+__global__ __launch_bounds__(256, NP == 2 ? 3 : 2) void sconv6_kernel(SConv6Args aa) {
     const SConvArgs& a = aa.c;
     constexpr int TCH = 32 * TCHW, TPX = 128;
     constexpr int PLANE_A = TCH * S6_ROWB, PLANE_B = TPX * S6_ROWB;
-    __shared__ __attribute__((aligned(16))) char smem[3 * PLANE_A + 3 * PLANE_B];
+    __shared__ __attribute__((aligned(16))) char smem[NP * PLANE_A + NP * PLANE_B];
     char* sA = smem;
-    char* sB = smem + 3 * PLANE_A;
+    char* sB = smem + NP * PLANE_A;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kg = lane >> 4;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void sconv6_kernel(SConv6Args aa) {
     const int cbase = a.cin_off + g * a.cin_g;
     const bool pointwise = a.kh == 1 && a.kw == 1;
 
-    uint4 ra[LA][3];
+    uint4 ra[LA][NP];
     f32x4 rb[LB][2];
     auto fetch = [&](int k0) {
         const int k = k0 + 8 * kq;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void sconv6_kernel(SConv6Args aa) {
 #pragma unroll
         for (int i = 0; i < LA; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
                 ra[i][p] = make_uint4(0, 0, 0, 0);
                 if (kok && wok[i]) ra[i][p] = *reinterpret_cast<const uint4*>(aa.wp + p * aa.plane_stride + wrow[i] + k);
             }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void sconv6_kernel(SConv6Args aa) {
         for (int i = 0; i < LA; ++i)
             if (r0 + 64 * i < TCH) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) *reinterpret_cast<uint4*>(sA + p * PLANE_A + (r0 + 64 * i) * S6_ROWB + kq * 16) = ra[i][p];
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(sA + p * PLANE_A + (r0 + 64 * i) * S6_ROWB + kq * 16) = ra[i][p];
             }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void sconv6_kernel(SConv6Args aa) {
             char* dst = sB + (r0 + 64 * i) * S6_ROWB + kq * 16;
             *reinterpret_cast<uint4*>(dst) = p0;
             *reinterpret_cast<uint4*>(dst + PLANE_B) = p1;
-            *reinterpret_cast<uint4*>(dst + 2 * PLANE_B) = p2;
+            if constexpr (NP == 3) *reinterpret_cast<uint4*>(dst + 2 * PLANE_B) = p2;
         }
     };
 
@@ -360,23 +360,25 @@ __global__ __launch_bounds__(256, 2) void sconv6_kernel(SConv6Args aa) {
         if (ci + 1 < nchunks) fetch((ci + 1) * SBK);
         const char* fa = sA + (wc * TCHW * 16 + l15) * S6_ROWB + kg * 16;
         const char* fb = sB + (wp_ * 64 + l15) * S6_ROWB + kg * 16;
-        bf16x8 bq[4][3];
+        bf16x8 bq[4][NP];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[j][p] = *reinterpret_cast<const bf16x8*>(fb + j * 16 * S6_ROWB + p * PLANE_B);
+            for (int p = 0; p < NP; ++p) bq[j][p] = *reinterpret_cast<const bf16x8*>(fb + j * 16 * S6_ROWB + p * PLANE_B);
 #pragma unroll
         for (int i = 0; i < TCHW; ++i) {
-            bf16x8 aq[3];
+            bf16x8 aq[NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) aq[p] = *reinterpret_cast<const bf16x8*>(fa + i * 16 * S6_ROWB + p * PLANE_A);
+            for (int p = 0; p < NP; ++p) aq[p] = *reinterpret_cast<const bf16x8*>(fa + i * 16 * S6_ROWB + p * PLANE_A);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 c = acc[i][j];
                 // smallest terms first
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[2], bq[j][0], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[0], bq[j][2], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[1], bq[j][1], c, 0, 0, 0);
+                if constexpr (NP == 3) {
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[2], bq[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[0], bq[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[1], bq[j][1], c, 0, 0, 0);
+                }
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[1], bq[j][0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[0], bq[j][1], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[0], bq[j][0], c, 0, 0, 0);
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void sconv6_kernel(SConv6Args aa) {
     }
 }
 
-template <int TCHW>
+template <int TCHW, int NP = 3>
 int launch_sconv6(const SConv6Args& aa, hipStream_t s) {
     constexpr int TCH = 32 * TCHW, TPX = 128;
     const SConvArgs& a = aa.c;
@@ -423,7 +425,7 @@ int launch_sconv6(const SConv6Args& aa, hipStream_t s) {
         vip_set_error("vip_conv2d_nhwc_s32x: grid too large (%ld x %d x %d)", gx, gy, a.groups);
         return VIP_ERR_UNSUPPORTED;
     }
-    hipLaunchKernelGGL((sconv6_kernel<TCHW>), dim3((unsigned)gx, gy, a.groups), dim3(256), 0, s, aa);
+    hipLaunchKernelGGL((sconv6_kernel<TCHW, NP>), dim3((unsigned)gx, gy, a.groups), dim3(256), 0, s, aa);
     return vip_launch_status("vip_conv2d_nhwc_s32x");
 }
 
@@ -488,4 +490,20 @@ extern "C" int vip_conv2d_nhwc_s32x(const float* x, const void* w_planes, int ld
     static const int narrow_max_k = getenv("VIP_S6_NARROW_MAXK") ? atoi(getenv("VIP_S6_NARROW_MAXK")) : 192;   // 192.7 -> 184.7 ms of GEMM per strict step
     if (aa.c.cout_g > 64 && aa.c.K > narrow_max_k) return launch_sconv6<4>(aa, s);
     return launch_sconv6<2>(aa, s);
+}
+
+/* The same with TWO bf16 terms per operand (planes 0 and 1 of the same w_planes tensor; x w ~= b0 c0 + b0 c1 + b1 c0: three MFMAs per
+ * block, 2^-17 of the product dropped - 64 x finer than fp16 storage, not f32 quality: measured member errors in DESIGN.md section 4). */
+extern "C" int vip_conv2d_nhwc_s32x2(const float* x, const void* w_planes, int ldwp, const float* bias, const float* residual, float* y,
+                                     const vip_conv_desc* d, void* stream) {
+    SConv6Args aa;
+    VIP_REQUIRE(ldwp > 0 && ldwp % 8 == 0, VIP_ERR_ALIGNMENT, "vip_conv2d_nhwc_s32x2: ldwp must be a positive multiple of 8");
+    const int st = sconv_fill("vip_conv2d_nhwc_s32x2", x, w_planes, bias, residual, y, d, ldwp, aa.c);
+    if (st != VIP_OK) return st;
+    aa.wp = (const unsigned short*)w_planes;
+    aa.ldwp = ldwp;
+    aa.plane_stride = (long)d->Cout * ldwp;
+    hipStream_t s = (hipStream_t)stream;
+    if (aa.c.cout_g > 64) return launch_sconv6<4, 2>(aa, s);
+    return launch_sconv6<2, 2>(aa, s);
 }
