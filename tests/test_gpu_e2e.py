@@ -286,6 +286,27 @@ def test_load_model_from_keras_h5(tmp_path, report):
     assert d <= 1e-6          # 0.0 when measured; both models are constructed (and bias-calibrated) separately
 
 
+@pytest.mark.gpu
+def test_load_model_from_savedmodel_directory(tmp_path, report):
+    """zoo.load_model on ckpts/<member directory>/ckpt (a Keras SavedModel directory: saved_model.pb + variables/ + keras_metadata.pb,
+    main.py:103-107,186-191), written here by the independent format writer of tests/_tfbundle_writer.py: the same predictions as the
+    model built from the variables, and the graph variant of keras_metadata.pb is honoured."""
+    import vipcup_amd  # noqa: F401
+    from tests import _tfbundle_writer as W
+    from vipcup_amd import pipeline, zoo
+    key = "vit_tiny_patch16_224"
+    spec = zoo.MEMBERS[key]
+    params = zoo.build_params(key)
+    d = tmp_path / "ckpts" / spec.ckpt_name / "ckpt"
+    W.write_savedmodel(str(d), {k: v.numpy() for k, v in params.items()}, None, block_size=4096)
+    x = pipeline.decode_jpegs([synth_jpeg(40 + i) for i in range(4)]).resized(spec.input_hw, spec.input_hw)
+    want = zoo.construct(spec, params).predict(x)
+    for path in (str(d), str(d / "saved_model.pb")):
+        got = zoo.load_model(path).predict(x)
+        assert (got - want).abs().max().item() <= 1e-6
+    report(f"[savedmodel] load_model({spec.ckpt_name}/ckpt): predictions equal to the model built from the variables")
+
+
 @pytest.mark.skipif(not os.path.exists("/opt/conda/bin/python3.9"), reason="no interpreter with h5py in this image")
 @pytest.mark.parametrize("key", ["efficientnet_v2t", "gcvit_tiny"])
 def test_load_model_variant_from_model_config(tmp_path, key, report, monkeypatch):

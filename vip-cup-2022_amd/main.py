@@ -9,7 +9,8 @@ Same contract: the input CSV has a ``filename`` column with paths relative to th
 it only in memory).  The ensemble manifest is ``ckpts/ckpts.json`` ([name, [H,W], idx],
 main.py:171-198); members whose graph is not built yet are reported and skipped only under ``--allow-missing``.
 
-Checkpoints: ``<script dir>/ckpts/<name>/ckpt/*.h5`` (Keras weight / model files, as in the reference) or ``*.npz`` (a flat dict of
+Checkpoints: ``<script dir>/ckpts/<name>/ckpt/*.h5`` (Keras weight / model files, as in the reference), else ``ckpt/saved_model.pb`` (a
+Keras SavedModel directory: its variables are read by ``tfbundle``), or ``*.npz`` (a flat dict of
 Keras-named arrays), one file per fold.
 The reference ships none (README.md:13) and raises when a directory is empty (main.py:194); so does this CLI,
 unless ``--synthetic`` asks for the seeded synthetic checkpoints.
@@ -114,6 +115,9 @@ def main(argv=None):
         spec = zoo.MEMBERS[key]
         assert [spec.input_hw, spec.input_hw] == list(dim), (name, dim)
         ckpts = sorted(glob(os.path.join(HERE, "ckpts", name, "ckpt", "*.npz")) + glob(os.path.join(HERE, "ckpts", name, "ckpt", "*.h5")))
+        sm_path = os.path.join(HERE, "ckpts", name, "ckpt", "saved_model.pb")
+        if not ckpts and os.path.isfile(sm_path):                  # SavedModel format, when there are no .h5 folds (main.py:186-191)
+            ckpts = [sm_path]
         if mi not in mine:
             if not ckpts and not a.synthetic:
                 raise ValueError(f"no checkpoints under ckpts/{name}/ckpt (pass --synthetic for seeded synthetic weights)")

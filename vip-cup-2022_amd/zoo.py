@@ -232,6 +232,11 @@ def read_checkpoint(path: str):
     if path.endswith((".h5", ".hdf5")):
         from . import h5lite
         arrays = h5lite.load_keras_weights(path)
+    elif os.path.basename(path) == "saved_model.pb" or os.path.isdir(path):
+        # a Keras SavedModel directory (main.py:103-104,186-194): the variables of variables/variables.{index,data-*} under their
+        # graph names (tfbundle: written from the published formats, never pinned against TensorFlow output - see its header)
+        from . import tfbundle
+        arrays = tfbundle.load_savedmodel_weights(path)
     else:
         arrays = dict(np.load(path).items())
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in arrays.items()}
@@ -261,7 +266,11 @@ def load_model(path: str, compile: bool = False, precision: str = None, bias_cal
     ``predict(dataset, steps, verbose) -> np.ndarray [n, C]`` of a Keras model.  ``precision`` / ``bias_calibration`` /
     ``calibration_batch``: see ``construct``; a strict model takes fp32 batches (``pipeline.build_dataset`` yields them when
     ``CFG.precision == "strict"`` or ``ops.PRECISION`` is)."""
-    model_name = os.path.basename(os.path.dirname(os.path.dirname(os.path.abspath(path))))
+    ap = os.path.abspath(path)
+    if os.path.isdir(ap):                       # the SavedModel form: main.py:103-104 hands load_model the ckpt DIRECTORY
+        ap = os.path.join(ap, "saved_model.pb")
+    path = ap
+    model_name = os.path.basename(os.path.dirname(os.path.dirname(ap)))
     key = by_ckpt_name(model_name)
     if key is None:
         raise ValueError(f"load_model: no graph for checkpoint directory {model_name!r}")
@@ -365,6 +374,9 @@ def variant_kwargs(spec: MemberSpec, info: dict) -> dict:
 
 def checkpoint_variant(spec: MemberSpec, path: str) -> dict:
     """constructor keyword arguments a checkpoint file asks for ({} for weight-only files and .npz)"""
+    if os.path.basename(path) == "saved_model.pb" or os.path.isdir(path):
+        from . import tfbundle
+        return variant_kwargs(spec, variant_from_model_config(tfbundle.load_savedmodel_config(path)))
     if not path.endswith((".h5", ".hdf5")):
         return {}
     from . import h5lite
