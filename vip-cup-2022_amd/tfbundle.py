@@ -261,8 +261,12 @@ class Bundle:
         if e.offset + e.size > data.shape[0]:
             raise BundleError(f"{name}: tensor bytes run past the data shard")
         raw = bytes(data[e.offset:e.offset + e.size])
-        if e.crc is not None and e.size <= CRC_TENSOR_CAP and e.dtype != DT_STRING and crc_unmask(e.crc) != crc32c(raw):
-            raise BundleError(f"{name}: tensor checksum mismatch")
+        if e.crc is not None and e.size <= CRC_TENSOR_CAP and e.dtype != DT_STRING:
+            # tensor_bundle.cc stores the MASKED crc32c of the tensor bytes; the plain value is accepted as well (this reader has never
+            # met TensorFlow's own output, and a false refusal of a good file helps nobody - a damaged tensor matches neither)
+            c = crc32c(raw)
+            if c != crc_unmask(e.crc) and c != e.crc:
+                raise BundleError(f"{name}: tensor checksum mismatch")
         return raw
 
     def tensor(self, name: str) -> np.ndarray:
