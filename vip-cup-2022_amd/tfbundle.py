@@ -8,8 +8,7 @@ port (footer with two block handles + magic 0xdb4775248b80fb57, prefix-compresse
 masked CRC32C trailer per block), ``tensor_bundle.proto`` (BundleHeaderProto, BundleEntryProto), the string-tensor layout of
 ``tensor_bundle.cc`` and ``trackable_object_graph.proto`` - and is exercised against an independent writer of the same formats
 (tests/_tfbundle_writer.py) plus damage tests.  It refuses what it does not implement (snappy-compressed blocks, sliced / partitioned
-variables, big-endian bundles, multi-shard files it cannot find) instead of guessing, and checks every block CRC and (up to a size cap)
-every tensor CRC.
+variables, big-endian bundles, multi-shard files it cannot find) instead of guessing, and checks every block CRC and every tensor CRC.
 
     load_savedmodel_weights(path)  ->  {Keras variable name: np.ndarray}      path = the SavedModel directory or its saved_model.pb
     load_savedmodel_config(path)   ->  the Keras model config (dict) from keras_metadata.pb, or None
@@ -25,7 +24,6 @@ TABLE_MAGIC = 0xDB4775248B80FB57
 FOOTER_LEN = 48
 CRC_MASK_DELTA = 0xA282EAD8
 OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
-CRC_TENSOR_CAP = 1 << 20          # tensors above this many bytes are not CRC-checked (pure-Python CRC32C: ~10 MB/s)
 
 # tensorflow/core/framework/types.proto
 DTYPES = {1: np.dtype("<f4"), 2: np.dtype("<f8"), 3: np.dtype("<i4"), 4: np.dtype("u1"), 5: np.dtype("<i2"), 6: np.dtype("i1"),
@@ -59,6 +57,71 @@ def crc32c(data: bytes, crc: int = 0) -> int:
     for b in data:
         c = tab[(c ^ b) & 0xFF] ^ (c >> 8)
     return c ^ 0xFFFFFFFF
+
+
+# Large tensors: the CRC is linear over GF(2), so the buffer is cut into 2^k equal chunks whose CRCs advance together (one numpy table
+# lookup per byte POSITION instead of per byte), and neighbouring chunk CRCs are then folded pairwise with the "append n zero bytes"
+# operator of zlib's crc32_combine - ~100 MB/s instead of ~5.
+def _gf2_times(mat, vec: int) -> int:
+    out, i = 0, 0
+    while vec:
+        if vec & 1:
+            out ^= mat[i]
+        vec >>= 1
+        i += 1
+    return out
+
+
+def _gf2_square(mat):
+    return [_gf2_times(mat, mat[i]) for i in range(32)]
+
+
+def _zeros_operator(nbytes: int):
+    """the 32 x 32 GF(2) matrix (as 32 column words) that advances a CRC register over nbytes zero bytes"""
+    odd = [0x82F63B78] + [1 << i for i in range(31)]        # one zero BIT
+    op = None
+    cur = _gf2_square(_gf2_square(_gf2_square(odd)))         # 8 bits = one byte
+    n = nbytes
+    while n:
+        if n & 1:
+            op = cur if op is None else [_gf2_times(cur, op[i]) for i in range(32)]
+        n >>= 1
+        if n:
+            cur = _gf2_square(cur)
+    return op if op is not None else [1 << i for i in range(32)]
+
+
+def crc32c_combine(crc1: int, crc2: int, len2: int) -> int:
+    """crc32c(A + B) from crc32c(A), crc32c(B), len(B)"""
+    return _gf2_times(_zeros_operator(len2), crc1) ^ crc2 if len2 else crc1
+
+
+def crc32c_fast(data) -> int:
+    """crc32c of a bytes-like / uint8 array of any size (numpy-vectorised above 64 KB)"""
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.reshape(-1).view(np.uint8)
+    n = a.shape[0]
+    if n < (1 << 16):
+        return crc32c(a.tobytes())
+    k = max(1, min(16, int(np.log2(n // 1024))))            # 2^k chunks of >= 1 KB
+    chunks = 1 << k
+    length = n // chunks
+    body = a[:chunks * length].reshape(chunks, length)
+    tab = np.asarray(_CRC_TAB, dtype=np.uint32)
+    c = np.full(chunks, 0xFFFFFFFF, dtype=np.uint32)
+    for j in range(length):
+        c = tab[(c ^ body[:, j]) & 0xFF] ^ (c >> np.uint32(8))
+    c ^= np.uint32(0xFFFFFFFF)
+    op, seg = _zeros_operator(length), length
+    while c.shape[0] > 1:                                    # fold pairs: crc(A + B) = op . crc(A) ^ crc(B)
+        left, right = c[0::2], c[1::2]
+        moved = np.zeros_like(left)
+        for bit in range(32):
+            moved ^= np.where((left >> np.uint32(bit)) & np.uint32(1), np.uint32(op[bit]), np.uint32(0))
+        c = moved ^ right
+        op, seg = _gf2_square(op), seg * 2
+    total = int(c[0])
+    tail = a[chunks * length:]
+    return crc32c_combine(total, crc32c(tail.tobytes()), tail.shape[0]) if tail.shape[0] else total
 
 
 def crc_mask(crc: int) -> int:
@@ -261,10 +324,10 @@ class Bundle:
         if e.offset + e.size > data.shape[0]:
             raise BundleError(f"{name}: tensor bytes run past the data shard")
         raw = bytes(data[e.offset:e.offset + e.size])
-        if e.crc is not None and e.size <= CRC_TENSOR_CAP and e.dtype != DT_STRING:
+        if e.crc is not None and e.dtype != DT_STRING:
             # tensor_bundle.cc stores the MASKED crc32c of the tensor bytes; the plain value is accepted as well (this reader has never
             # met TensorFlow's own output, and a false refusal of a good file helps nobody - a damaged tensor matches neither)
-            c = crc32c(raw)
+            c = crc32c_fast(raw)
             if c != crc_unmask(e.crc) and c != e.crc:
                 raise BundleError(f"{name}: tensor checksum mismatch")
         return raw
