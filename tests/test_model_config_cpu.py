@@ -33,7 +33,7 @@ RS = functional([layer("InputLayer", batch_input_shape=[None, 200, 200, 3], name
 
 def test_functional_graph():
     info = zoo.variant_from_model_config(RS)
-    assert info == {"input_hw": (200, 200), "first_strides": 1, "classes": 2, "head_act": "softmax"}
+    assert info == {"input_hw": (200, 200), "stem_strides": 1, "stem_layer": "stem_conv_1", "n_layers": 7, "classes": 2, "head_act": "softmax"}
     assert zoo.variant_kwargs(zoo.MEMBERS["resnet_rs50"], info) == {"classes": 2, "first_strides": 1}
     # defaults are not passed on; a sigmoid on two classes (multi-label) is
     dflt = functional([layer("InputLayer", batch_input_shape=[None, 200, 200, 3]), layer("Conv2D", name="stem_conv", strides=[2, 2]),
@@ -41,8 +41,36 @@ def test_functional_graph():
     assert zoo.variant_kwargs(zoo.MEMBERS["efficientnet_v2t"], zoo.variant_from_model_config(dflt)) == {}
     ml = functional([layer("Conv2D", name="stem_conv", strides=2), layer("Dense", name="predictions", units=2, activation="sigmoid")])
     assert zoo.variant_kwargs(zoo.MEMBERS["eca_nfnet_l0"], zoo.variant_from_model_config(ml)) == {"classes": 2, "classifier_activation": "sigmoid"}
-    lin = functional([layer("Dense", name="predictions", units=1, activation=None)])
+    lin = functional([layer("Conv2D", name="stem_1_conv", strides=[2, 2]), layer("Dense", name="predictions", units=1, activation=None)])
     assert zoo.variant_kwargs(zoo.MEMBERS["resnest50"], zoo.variant_from_model_config(lin)) == {"classifier_activation": "linear"}
+
+
+def test_stem_stride_is_family_aware():
+    """the serialised class of the NFNet stem is `nfnets>ScaledStandardizedConv2D` (nfnets.py:41), and HorNet's stem convolution
+    runs at first_strides * 2 (hornet.py:144) - both with the class names Keras really writes."""
+    nf = functional([layer("InputLayer", batch_input_shape=[None, 200, 200, 3]),
+                     layer("ZeroPadding2D", name="stem_1_pad"),
+                     layer("nfnets>ScaledStandardizedConv2D", name="stem_1_conv", strides=[1, 1], filters=16),
+                     layer("nfnets>ScaledStandardizedConv2D", name="stem_2_conv", strides=[1, 1], filters=32),
+                     layer("Dense", name="predictions", units=1, activation="sigmoid")])
+    assert zoo.variant_kwargs(zoo.MEMBERS["eca_nfnet_l0"], zoo.variant_from_model_config(nf)) == {"first_strides": 1}
+    nf2 = functional([layer("nfnets>ScaledStandardizedConv2D", name="stem_1_conv", strides=[2, 2]),
+                      layer("Dense", name="predictions", units=1, activation="sigmoid")])
+    assert zoo.variant_kwargs(zoo.MEMBERS["eca_nfnet_l0"], zoo.variant_from_model_config(nf2)) == {}
+    # HorNet: default first_strides = 2 -> stem stride 4; first_strides = 1 -> stem stride 2
+    hn = lambda st: functional([layer("InputLayer", batch_input_shape=[None, 200, 200, 3]),
+                                layer("Conv2D", name="stem_conv", strides=[st, st], kernel_size=[4, 4]),
+                                layer("DepthwiseConv2D", name="stack1_block1_gnconv_dw", strides=[1, 1]),
+                                layer("Dense", name="predictions", units=1, activation="sigmoid")])
+    assert zoo.variant_kwargs(zoo.MEMBERS["hornet_base"], zoo.variant_from_model_config(hn(4))) == {}
+    assert zoo.variant_kwargs(zoo.MEMBERS["hornet_base"], zoo.variant_from_model_config(hn(2))) == {"first_strides": 1}
+    with pytest.raises(ValueError):
+        zoo.variant_kwargs(zoo.MEMBERS["hornet_base"], zoo.variant_from_model_config(hn(3)))
+    # a depthwise layer is never the stem; a graph with layers and no stem convolution is refused, not defaulted
+    nostem = functional([layer("InputLayer", batch_input_shape=[None, 200, 200, 3]), layer("DepthwiseConv2D", name="dw", strides=[1, 1]),
+                         layer("Dense", name="predictions", units=1, activation="sigmoid")])
+    with pytest.raises(ValueError):
+        zoo.variant_kwargs(zoo.MEMBERS["resnet_rs50"], zoo.variant_from_model_config(nostem))
 
 
 def test_wrong_input_size_is_refused():

@@ -106,6 +106,31 @@ def test_dataset_stream_semantics(tmp_path):
     assert os.path.isdir(tmp_path / "cache")
 
 
+def test_tta_flag_cache_survives_batches_that_span_many_passes(tmp_path, monkeypatch):
+    """10 images in batches of 128 with tta > 1 - one batch covers 13 passes; the per-pass flag cache used to evict passes the
+    batch still needed (KeyError 0).  Also a second walk that restarts at pass 0 with a full cache."""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import ensemble, pipeline
+    paths = _write_images(tmp_path, 10)
+    CFG = _CFG()
+    CFG.img_size, CFG.seed, CFG.num_classes = [24, 24], 42, 1
+    seen = []
+
+    def fake_augment(batch, flip_h, flip_v, gray):
+        seen.append(np.stack([np.asarray(flip_h), np.asarray(flip_v), np.asarray(gray)], 1))
+        return batch
+    monkeypatch.setattr(pipeline, "apply_augment", fake_augment)
+    ds = pipeline.build_dataset(paths, batch_size=128, repeat=True, shuffle=False, augment=True, CFG=CFG, decode_fn=_pil_decode, device="cpu")
+    for _ in range(2):                                     # the second predict() restarts the stream at pass 0
+        it = iter(ds)
+        for _ in range(3):
+            next(it)
+    assert len(seen) >= 6 and all(s.shape == (128, 3) for s in seen[:6])
+    want = np.stack([ensemble.tta_flags_pass(10, t, 42)[i] for t in range(13) for i in range(10)])[:128]
+    assert np.array_equal(seen[0], want) and np.array_equal(seen[3], want)
+    assert len(ds._flags) <= 14
+
+
 def test_workspace_query_and_kernel_name_are_exported():
     import ctypes as C
     import vipcup_amd  # noqa: F401

@@ -206,12 +206,18 @@ class Dataset:
                 batch = self.augment_fn(batch)
             else:       # apply_augment (dataset/augment.py:153-182): seeded draws per (pass, image) - TF's RNG stream is not reproducible
                 from .ensemble import tta_flags_pass
-                for t in {t for _, t in items}:             # the draws of a pass are a function of (seed, pass): built once per pass
+                need = {t for _, t in items}                # the draws of a pass are a function of (seed, pass): built once per pass
+                for t in need:
                     if t not in self._flags:
-                        if len(self._flags) > 4:             # a repeating dataset walks the passes in order: keep only recent ones
-                            self._flags.pop(min(self._flags))
                         self._flags[t] = tta_flags_pass(len(self.paths), t, self.seed)
                 sel = np.stack([self._flags[t][i] for i, t in items])
+                # trimmed only AFTER the batch is assembled and never below what it used: a batch may span many passes (fewer images
+                # than batch_size / 5) or straddle the restart of a second predict() - a repeating dataset walks the passes in order
+                for t in sorted(self._flags):
+                    if len(self._flags) <= max(4, len(need)):
+                        break
+                    if t not in need:
+                        del self._flags[t]
                 batch = apply_augment(batch, sel[:, 0], sel[:, 1], sel[:, 2])
         if self.labels is None:
             return batch

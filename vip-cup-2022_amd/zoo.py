@@ -301,25 +301,29 @@ def _walk_layers(cfg):
 def variant_from_model_config(cfg: Optional[dict]) -> dict:
     """What a Keras ``model_config`` says about the arguments the member constructors expose:
     ``input_hw`` (InputLayer batch_input_shape), ``first_strides`` (a custom layer's own ``first_strides`` entry - gcvit ``Stem``,
-    layers/embedding.py:25-29 - else the strides of the first Conv2D: the stem conv of resnet_rs_model.py:97-104 and of the kecam
-    graphs), ``classes`` and ``head_act`` (units / activation of the LAST Dense: resnet_rs_model.py:474-476, common_layers.py:278-283),
+    layers/embedding.py:25-29) or else ``stem_strides`` / ``stem_layer`` (RAW stride and name of the first convolution-class layer -
+    ``Conv2D`` or a registered subclass like ``nfnets>ScaledStandardizedConv2D``; ``variant_kwargs`` maps it onto the family's
+    ``first_strides``: HorNet's stem runs at twice that), ``n_layers``, ``classes`` and ``head_act`` (units / activation of the LAST Dense: resnet_rs_model.py:474-476, common_layers.py:278-283),
     and for a tfimm model (class ``...>ViT`` / ``...>ConvNeXt`` serialised by tfimm/models/serialization.py:21-89 as its config
     dataclass) the dataclass fields themselves under ``tfimm_cfg``.  Keys that the file does not determine are absent."""
     out: dict = {}
     if not cfg:
         return out
-    first_conv, last_dense = None, None
+    first_conv, last_dense, n_layers = None, None, 0
     for node in _walk_layers(cfg):
         cname = str(node.get("class_name", ""))
         c = node.get("config") if isinstance(node.get("config"), dict) else {}
         short = cname.split(">")[-1]
+        n_layers += 1
         if short == "InputLayer" and "input_hw" not in out:
             shp = c.get("batch_input_shape") or c.get("batch_shape")
             if shp and len(shp) == 4 and shp[1] and shp[2]:
                 out["input_hw"] = (int(shp[1]), int(shp[2]))
         if "first_strides" in c and "first_strides" not in out:
             out["first_strides"] = int(c["first_strides"])
-        if short == "Conv2D" and first_conv is None:
+        # the stem convolution: the first layer of ANY convolution class that carries strides - plain `Conv2D`, or a registered
+        # subclass such as `nfnets>ScaledStandardizedConv2D` (nfnets.py:41-81, the ECA-NFNet stem) - depthwise / separable ones excepted
+        if first_conv is None and short.endswith("Conv2D") and not short.startswith(("Depthwise", "Separable")) and c.get("strides"):
             first_conv = c
         if short == "Dense":
             last_dense = c
@@ -332,9 +336,12 @@ def variant_from_model_config(cfg: Optional[dict]) -> dict:
             for k_src, k_dst in (("num_classes", "classes"), ("head_act", "head_act"), ("first_strides", "first_strides")):
                 if k_src in c:
                     out[k_dst] = c[k_src]
-    if "first_strides" not in out and first_conv is not None and first_conv.get("strides"):
+    if "first_strides" not in out and first_conv is not None:
         st = first_conv["strides"]
-        out["first_strides"] = int(st[0] if isinstance(st, (list, tuple)) else st)
+        # RAW stride of the stem convolution: variant_kwargs turns it into the constructor's first_strides per family
+        out["stem_strides"] = int(st[0] if isinstance(st, (list, tuple)) else st)
+        out["stem_layer"] = str(first_conv.get("name", ""))
+    out["n_layers"] = n_layers
     if last_dense is not None and "classes" not in out:
         out["classes"] = int(last_dense["units"])
         out["head_act"] = last_dense.get("activation") or "linear"
@@ -360,6 +367,20 @@ def variant_kwargs(spec: MemberSpec, info: dict) -> dict:
         if classes is not None and "nb_classes" not in kw:
             kw["nb_classes"] = classes
         return kw
+    if fs is None and "stem_strides" in info:
+        # the constructor argument behind the stem convolution's stride: HorNet's stem runs at first_strides * 2 (kecam
+        # hornet/hornet.py:144), every other family's at first_strides itself (resnet_rs_model.py:97-104, aotnet.py:326,
+        # efficientnet_v2.py:155-156, nfnets.py:182-191)
+        ss = int(info["stem_strides"])
+        if fam == "hornet_ref":
+            if ss % 2:
+                raise ValueError(f"{spec.ckpt_name}: stem convolution {info.get('stem_layer')!r} has stride {ss}; HorNet's is 2 * first_strides")
+            fs = ss // 2
+        else:
+            fs = ss
+    if fs is None and info.get("n_layers", 0) > 1 and fam != "gcvit_ref":
+        raise ValueError(f"{spec.ckpt_name}: the checkpoint's model_config lists {info['n_layers']} layers but no stem convolution with "
+                         "strides could be identified - refusing to assume first_strides")
     if classes is not None and classes != 1:
         kw["classes"] = int(classes)
     if fs is not None and fs != 2:
