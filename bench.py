@@ -49,7 +49,7 @@ def parse():
                     help="auto (= ensemble8) | ensemble8 | ensemble (7 manifest members) | ensemble4 | <member name>; "
                          "suffix -resident: start from decoded pixels in HBM")
     ap.add_argument("--shard", default="images", choices=["images", "members", "hybrid"])
-    ap.add_argument("--precision", default=None, choices=["fast", "strict"],
+    ap.add_argument("--precision", default=None, choices=["fast", "strict", "f32"],
                     help="fast (default): fp16 storage; strict: fp32 storage + fp32 matrix arithmetic (every member logit within 1e-3 "
                          "of the fp32 oracle).  The default run times the strict mode too and reports it under detail.strict_precision")
     ap.add_argument("--distinct-batches", type=int, default=20,

@@ -382,6 +382,47 @@ int vip_prob_to_score_f32(const float* prob, float* score, int B, int N, void* s
 int vip_ensemble_mean_f32(const float* scores, float* mean, int M, int n, long ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * STRICT precision path, packed storage (entry points ending in _h2) - the default of `--precision strict` since round 4.
+ * An activation or weight value v is TWO fp16 terms, hi = rn16(v) and lo = rn16(v - hi): 2^-22 relative for |v| >= 2^-3, 2^-25
+ * absolute below, |v| <= 65504.  Layout: 8 consecutive channels c0..c0+7 (c0 % 8 == 0) of a row = 32 bytes [hi x 8][lo x 8] - four
+ * bytes per element like fp32; every channel count, stride and offset is a multiple of 8 and is given in ELEMENTS.  Contractions run
+ * on v_mfma_f32_16x16x32_f16, three per fragment pair (w_lo x_hi + w_hi x_lo + w_hi x_hi; w_lo x_lo, 2^-22 of the product, is dropped)
+ * with fp32 accumulation: fp32-quality results at 1/3 of the fp16 matrix rate instead of 1/6 (the bf16 x 3 splits of _s32x) or 1/16
+ * (_s32), and producers store the split ONCE so that consumers load MFMA fragments with no conversion.  Everything else (LayerNorm,
+ * pooling, depthwise filters, softmax, activations) is fp32 arithmetic on the joined value.
+ * `status`: optional device word; a producer that meets a value outside the fp16 range (or a NaN) stores VIP_H2_OVERFLOW there -
+ * the caller checks it after the forward pass and falls back to the fp32-storage path (_s32).  Same reference call sites as _s32.
+ * vip_pack_h2 / vip_unpack_h2 convert fp32 rows <-> packed rows (n elements, n % 8 == 0).
+ * ------------------------------------------------------------------------------------------ */
+#define VIP_H2_OVERFLOW 1
+int vip_pack_h2(const float* x, void* y, long n, int* status, void* stream);
+int vip_unpack_h2(const void* x, float* y, long n, void* stream);
+/* w: packed rows [Cout][ldw halfs] of (W * w_scale) ([kh][kw][Cin_g] order, 8 k = [hi x 8][lo x 8]; ldw % 16 == 0, zero padded),
+ * bias = b * w_scale (fp32), out_scale = 1 / w_scale (a power of two chosen by the caller so that the low halves are fp16 normals). */
+int vip_conv2d_nhwc_h2(const void* x, const void* w, const float* bias, const void* residual, void* y, const vip_conv_desc* d,
+                       float out_scale, int* status, void* stream);
+int vip_conv2d_kernel_name_h2(const vip_conv_desc* d, int has_residual, char* name, size_t cap);
+/* every other operator, arguments as the _s32 form (strict_ops.hip: one kernel template, two storages); fp32 parameters (LayerNorm
+ * gamma / beta, depthwise filters, head matrices, relative-position table) and fp32 head outputs as there */
+int vip_dwconv2d_nhwc_h2(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k, int stride,
+                         int pt, int pl, int Ho, int Wo, int act, int* status, void* stream);
+int vip_layernorm_h2(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps, int* status, void* stream);
+int vip_pool2d_nhwc_h2(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int k, int stride, int pt, int pl, int Ho,
+                       int Wo, int mode, int* status, void* stream);
+int vip_global_avgpool_h2(const void* x, void* y, int B, int HW, int C, int ldx, int* status, void* stream);
+int vip_scale_add_act_h2(const void* x, const void* scale, const void* residual, void* y, void* y2, int B, int HW, int C, int act,
+                         int act2, int* status, void* stream);
+int vip_radix_combine_h2(const void* x, const void* scale, void* y, int B, int HW, int C, int radix, int* status, void* stream);
+int vip_mul_h2(const void* a, const void* b, void* y, long rows, int C, int lda, int a_off, int ldb, int b_off, int ldy, int y_off,
+               int* status, void* stream);
+int vip_vit_tokens_h2(const void* patches, const void* cls, const void* pos, void* out, int B, int NP, int D, int* status, void* stream);
+int vip_gap_ln_dense_h2(const void* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias, float* out,
+                        int B, int HW, int C, int ldx, long img_stride, int N, void* stream);
+int vip_window_attn_fwd_h2(const void* qkv, const void* q_global, const float* bias_table, void* out, int B, int Hp, int Wp, int C,
+                           int heads, int ws, int nq, float scale, int* status, void* stream);
+int vip_mhsa_fwd_h2(const void* qkv, void* out, int B, int N, int D, int heads, float scale, int* status, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * STRICT precision path (entry points ending in _s32): the same operators with fp32 storage and fp32 arithmetic.
  *
  * The reference computes in fp32 (main.py:107-109: tf.keras.models.load_model(...).predict, no mixed-precision policy anywhere)

@@ -1,6 +1,8 @@
-"""GPU parity of the STRICT precision path (fp32 storage, f32-quality matrix arithmetic, fp32 activations; csrc/strict_*.hip): every
-operator against the fp32 CPU oracle at fp32 round-off, and every ensemble member's CALIBRATED logit within BASELINE.json's
-1e-3 (the mode in which the stated tolerance holds member by member - the fp16 path sits at its storage floor, tests/_parity.py)."""
+"""GPU parity of the two STRICT precision modes against the fp32 CPU oracle - every operator at fp32 round-off, every ensemble member's
+CALIBRATED logit within BASELINE.json's 1e-3 (the fp16 path sits at its storage floor, tests/_parity.py):
+  "strict": packed fp16 (hi, lo) pair storage, three fp16 MFMAs per fragment pair (csrc/conv_h2.hip = the fast path's GEMM kernels
+            instantiated for this storage, csrc/strict_ops.hip<SH2>) - the default of --precision strict since round 4;
+  "f32":    fp32 storage, f32-quality matrix arithmetic (csrc/strict_conv.hip, strict_ops.hip<SF32>) - round 3's strict mode."""
 import math
 import os
 
@@ -25,11 +27,24 @@ def _ops():
     return ops
 
 
+MODES = ["strict", "f32"]
+
+
 def dev(t):
+    """a PARAMETER (fp32 in both modes)"""
     return t.to(torch.float32).cuda().contiguous()
 
 
+def A(t, mode):
+    """an ACTIVATION in the mode's storage"""
+    d = dev(t)
+    return _ops().pack_h2(d) if mode == "strict" else d
+
+
 def check(report, name, got, ref, tol=TOL_OP):
+    if got.dtype == torch.int32:
+        got = _ops().unpack_h2(got)
+        _ops().h2_check(name)
     got = got.float().cpu()
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     scale = ref.abs().max().item() + 1e-6
@@ -58,14 +73,19 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("gemm", ["bf16x3", "f32", "bf16x2"])
+@pytest.mark.parametrize("gemm", ["h2", "bf16x3", "f32", "bf16x2"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:9]))
 def test_conv2d_strict(case, gemm, report, monkeypatch):
-    """the STRICT GEMM arithmetics: three-term bf16 splits on six bf16 MFMAs (the default) and the f32-input MFMA - f32 quality, 2e-5 -
-    and the opt-in two-term split (three MFMAs, 2^-17 of each product dropped: held to 1e-4 of the output scale)"""
+    """the STRICT GEMM arithmetics: "h2" = packed fp16 pairs, three fp16 MFMAs (precision "strict"); in precision "f32": three-term bf16
+    splits on six bf16 MFMAs (the default there) and the f32-input MFMA - all f32 quality, 2e-5 - and the opt-in two-term bf16 split
+    (three MFMAs, 2^-17 of each product dropped: held to 1e-4 of the output scale)"""
     ops = _ops()
-    monkeypatch.setattr(ops, "STRICT_GEMM", gemm)
+    mode = "strict" if gemm == "h2" else "f32"
+    if gemm != "h2":
+        monkeypatch.setattr(ops, "STRICT_GEMM", gemm)
     B, H, W, Cin, Cout, k, s, pad, groups, act, use_res = case
+    if mode == "strict" and ((Cin // groups) % 8 or (Cout // groups) % 8):
+        pytest.skip("packed storage: channel counts are multiples of 8 (models pad, as on the fp16 path)")
     g = torch.Generator().manual_seed(hash(case[:9]) % (2 ** 31))
     x = torch.randn(B, H, W, Cin, generator=g)
     w = torch.randn(k, k, Cin // groups, Cout, generator=g) / math.sqrt(k * k * Cin / groups)
@@ -75,16 +95,17 @@ def test_conv2d_strict(case, gemm, report, monkeypatch):
     if use_res:
         res = torch.randn(*ref.shape, generator=g)
         ref = ref + res
-    with ops.precision("strict"):
+    with ops.precision(mode):
         cw = ops.make_conv_weight(w, bias, groups=groups)
-    assert cw.strict and cw.w.dtype == torch.float32
-    got = ops.conv2d(dev(x), cw, stride=s, pad=pad, act=act, residual=None if res is None else dev(res))
+    assert cw.kind == ("h2" if mode == "strict" else "s32")
+    got = ops.conv2d(A(x, mode), cw, stride=s, pad=pad, act=act, residual=None if res is None else A(res, mode))
     torch.cuda.synchronize()
-    assert got.dtype == torch.float32
+    assert got.dtype == ops.act_dtype(mode)
     check(report, f"conv2d[{gemm}] {case}", got, ref, tol=1e-4 if gemm == "bf16x2" else TOL_OP)
 
 
-def test_conv2d_strict_channel_slices_and_gate(report):
+@pytest.mark.parametrize("mode", MODES)
+def test_conv2d_strict_channel_slices_and_gate(mode, report):
     """cin_off / cout_off (concat-free splits and joins), act_post after the residual, and a squeeze-excite gate"""
     ops = _ops()
     g = torch.Generator().manual_seed(5)
@@ -92,88 +113,97 @@ def test_conv2d_strict_channel_slices_and_gate(report):
     w = torch.randn(1, 1, 32, 48, generator=g) / math.sqrt(32)
     b = torch.randn(48, generator=g) * 0.1
     res = torch.randn(2, 11, 9, 48, generator=g)
-    with ops.precision("strict"):
+    with ops.precision(mode):
         cw = ops.make_conv_weight(w, b)
-    out = torch.zeros((2, 11, 9, 112), dtype=torch.float32, device="cuda")
-    ops.conv2d(dev(x), cw, residual=dev(res), act_post="relu", out=out, cin_off=32, cout_off=64)
+    out = torch.zeros((2, 11, 9, 112), dtype=ops.act_dtype(mode), device="cuda")       # all-zero bits are 0.0 in both storages
+    ops.conv2d(A(x, mode), cw, residual=A(res, mode), act_post="relu", out=out, cin_off=32, cout_off=64)
     ref = torch.relu(R.conv2d(x[..., 32:64], w, b) + res)
-    check(report, "conv2d slices", out[..., 64:112], ref)
-    assert float(out[..., :64].abs().max()) == 0.0
+    full = ops.unpack_h2(out) if mode == "strict" else out
+    check(report, "conv2d slices", full[..., 64:112].contiguous(), ref)
+    assert float(full[..., :64].abs().max()) == 0.0
     gate = torch.rand(2, 32, generator=g)
     x2 = torch.randn(2, 5, 5, 32, generator=g)
-    got = ops.conv2d(dev(x2), cw, gate=dev(gate))
+    got = ops.conv2d(A(x2, mode), cw, gate=A(gate, mode))
     check(report, "conv2d gate", got, R.conv2d(x2 * gate[:, None, None, :], w, b))
 
 
-def test_dense_mlp_se_strict(report):
+@pytest.mark.parametrize("mode", MODES)
+def test_dense_mlp_se_strict(mode, report):
     ops = _ops()
     g = torch.Generator().manual_seed(6)
     x = torch.randn(3, 50, 96, generator=g)
     k1, b1 = torch.randn(96, 384, generator=g) / math.sqrt(96), torch.randn(384, generator=g) * 0.1
     k2, b2 = torch.randn(384, 96, generator=g) / math.sqrt(384), torch.randn(96, generator=g) * 0.1
     gam, bet = 1 + 0.1 * torch.randn(96, generator=g), 0.1 * torch.randn(96, generator=g)
-    with ops.precision("strict"):
+    with ops.precision(mode):
         fc1, fc2 = ops.make_dense_weight(k1, b1), ops.make_dense_weight(k2, b2)
-    got = ops.mlp(dev(x), fc1, fc2, act="gelu", residual=dev(x), ln=(dev(gam), dev(bet), 1e-5))
+    got = ops.mlp(A(x, mode), fc1, fc2, act="gelu", residual=A(x, mode), ln=(dev(gam), dev(bet), 1e-5))
     ref = x + R.dense(R.act(R.dense(R.layernorm(x, gam, bet, 1e-5), k1, b1), "gelu"), k2, b2)
     check(report, "mlp", got, ref)
     xs = torch.randn(4, 7, 7, 96, generator=g)
-    s = ops.se_gate(dev(xs), fc1, fc2, "silu", "sigmoid")
-    assert s.shape == (4, 96) and s.dtype == torch.float32
+    s = ops.se_gate(A(xs, mode), fc1, fc2, "silu", "sigmoid")
+    assert s.shape == (4, 96) and s.dtype == ops.act_dtype(mode)
     sref = torch.sigmoid(R.dense(R.act(R.dense(xs.mean((1, 2)), k1, b1), "silu"), k2, b2))
     check(report, "se_gate", s, sref)
-    y = ops.scale_add_act(dev(xs), s, dev(xs), "relu")
+    y = ops.scale_add_act(A(xs, mode), s, A(xs, mode), "relu")
     check(report, "scale_add_act", y, torch.relu(xs * sref[:, None, None, :] + xs))
-    y1, y2 = ops.scale_add_act(dev(xs), None, None, None, act2="silu")
+    y1, y2 = ops.scale_add_act(A(xs, mode), None, None, None, act2="silu")
     check(report, "scale_add_act second output", y2, R.act(xs, "silu"))
-    assert torch.equal(y1.cpu(), xs)
+    if mode == "f32":
+        assert torch.equal(y1.cpu(), xs)
+    else:
+        check(report, "scale_add_act identity", y1, xs, tol=3e-7)
 
 
 @pytest.mark.parametrize("k,s,pad,act", [(3, 1, (1, 1, 1, 1), "gelu"), (3, 2, (0, 1, 0, 1), "silu"), (5, 1, (2, 2, 2, 2), "silu"),
                                          (5, 2, (1, 2, 1, 2), None), (7, 1, (3, 3, 3, 3), None)])
-def test_dwconv_strict(k, s, pad, act, report):
+@pytest.mark.parametrize("mode", MODES)
+def test_dwconv_strict(k, s, pad, act, mode, report):
     ops = _ops()
     g = torch.Generator().manual_seed(k * 10 + s)
     x = torch.randn(2, 15, 13, 40, generator=g)
     w = torch.randn(k, k, 40, 1, generator=g) / k
     b = torch.randn(40, generator=g) * 0.1
-    got = ops.dwconv2d(dev(x), ops.make_dw_weight(w), dev(b), k, s, pad, act=act)
+    got = ops.dwconv2d(A(x, mode), ops.make_dw_weight(w), dev(b), k, s, pad, act=act)
     check(report, f"dwconv k{k} s{s}", got, R.act(R.dwconv2d(x, w, b, s, pad), act))
 
 
-def test_norm_pool_heads_strict(report):
+@pytest.mark.parametrize("mode", MODES)
+def test_norm_pool_heads_strict(mode, report):
     ops = _ops()
+    act = lambda t: A(t, mode)  # noqa: E731
     g = torch.Generator().manual_seed(8)
     for C in (64, 96, 768, 1536):
         x = torch.randn(37, C, generator=g) * 2 + 0.3
         gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
-        check(report, f"layernorm C={C}", ops.layernorm(dev(x), dev(gam), dev(bet), 1e-6), R.layernorm(x, gam, bet, 1e-6))
+        check(report, f"layernorm C={C}", ops.layernorm(act(x), dev(gam), dev(bet), 1e-6), R.layernorm(x, gam, bet, 1e-6))
     x = torch.randn(2, 13, 11, 24, generator=g)
-    check(report, "avgpool same", ops.pool2d(dev(x), 2, 2, (0, 1, 0, 1), ops.POOL_AVG_VALID), R.avgpool_same(x, 2, 2))
-    check(report, "avgpool full", ops.pool2d(dev(x), 3, 2, (1, 1, 1, 1), ops.POOL_AVG_FULL), R.avgpool_valid(x, 3, 2, (1, 1, 1, 1)))
-    check(report, "maxpool zero-pad", ops.pool2d(dev(x), 3, 2, (1, 1, 1, 1), ops.POOL_MAX_ZEROPAD), R.maxpool_valid(x, 3, 2, (1, 1, 1, 1)))
-    check(report, "zero-pad copy", ops.pool2d(dev(x), 1, 1, (0, 1, 1, 2), ops.POOL_MAX_ZEROPAD), R.zero_pad(x, (0, 1, 1, 2)))
-    check(report, "crop", ops.pool2d(dev(x), 1, 1, (0, 0, 0, 0), ops.POOL_MAX_ZEROPAD, out_hw=(9, 7)), x[:, :9, :7].contiguous())
-    check(report, "global_avgpool", ops.global_avgpool(dev(x), split=True), x.mean((1, 2)))
+    check(report, "avgpool same", ops.pool2d(act(x), 2, 2, (0, 1, 0, 1), ops.POOL_AVG_VALID), R.avgpool_same(x, 2, 2))
+    check(report, "avgpool full", ops.pool2d(act(x), 3, 2, (1, 1, 1, 1), ops.POOL_AVG_FULL), R.avgpool_valid(x, 3, 2, (1, 1, 1, 1)))
+    check(report, "maxpool zero-pad", ops.pool2d(act(x), 3, 2, (1, 1, 1, 1), ops.POOL_MAX_ZEROPAD), R.maxpool_valid(x, 3, 2, (1, 1, 1, 1)))
+    check(report, "zero-pad copy", ops.pool2d(act(x), 1, 1, (0, 1, 1, 2), ops.POOL_MAX_ZEROPAD), R.zero_pad(x, (0, 1, 1, 2)))
+    check(report, "crop", ops.pool2d(act(x), 1, 1, (0, 0, 0, 0), ops.POOL_MAX_ZEROPAD, out_hw=(9, 7)), x[:, :9, :7].contiguous())
+    check(report, "global_avgpool", ops.global_avgpool(act(x), split=True), x.mean((1, 2)))
     wn, bn = torch.randn(3, 24, generator=g), torch.randn(3, generator=g)
-    check(report, "gap_dense", ops.gap_dense_f32(dev(x), dev(wn), dev(bn)), x.mean((1, 2)) @ wn.t() + bn)
+    check(report, "gap_dense", ops.gap_dense_f32(act(x), dev(wn), dev(bn)), x.mean((1, 2)) @ wn.t() + bn)
     gam, bet = 1 + 0.1 * torch.randn(24, generator=g), 0.1 * torch.randn(24, generator=g)
-    check(report, "gap_ln_dense", ops.gap_ln_dense_f32(dev(x), dev(gam), dev(bet), 1e-6, dev(wn), dev(bn)),
+    check(report, "gap_ln_dense", ops.gap_ln_dense_f32(act(x), dev(gam), dev(bet), 1e-6, dev(wn), dev(bn)),
           R.layernorm(x.mean((1, 2)), gam, bet, 1e-6) @ wn.t() + bn)
     t = torch.randn(3, 17, 24, generator=g)
-    check(report, "cls_dense", ops.cls_dense_f32(dev(t), dev(wn), dev(bn)), t[:, 0] @ wn.t() + bn)
+    check(report, "cls_dense", ops.cls_dense_f32(act(t), dev(wn), dev(bn)), t[:, 0] @ wn.t() + bn)
     cls, pos = torch.randn(24, generator=g), torch.randn(18, 24, generator=g)
-    check(report, "vit_tokens", ops.vit_tokens(dev(t), dev(cls), dev(pos)),
+    check(report, "vit_tokens", ops.vit_tokens(act(t), act(cls), act(pos)),
           torch.cat([cls.expand(3, 1, 24), t], 1) + pos[None])
     xr, sr = torch.randn(2, 5, 6, 32, generator=g), torch.rand(2, 32, generator=g)
-    check(report, "radix_combine", ops.radix_combine(dev(xr), dev(sr), 2),
+    check(report, "radix_combine", ops.radix_combine(act(xr), act(sr), 2),
           xr[..., :16] * sr[:, None, None, :16] + xr[..., 16:] * sr[:, None, None, 16:])
     a, b = torch.randn(2, 5, 48, generator=g), torch.randn(2, 5, 32, generator=g)
-    check(report, "mul", ops.mul(dev(a), dev(b), 16, 32, 8), a[..., 32:48] * b[..., 8:24])
+    check(report, "mul", ops.mul(act(a), act(b), 16, 32, 8), a[..., 32:48] * b[..., 8:24])
 
 
 @pytest.mark.parametrize("ws,heads,nwin,glob", [(7, 2, (2, 3), False), (7, 4, (1, 2), True), (14, 8, (1, 1), False), (14, 8, (1, 1), True)])
-def test_window_attention_strict(ws, heads, nwin, glob, report):
+@pytest.mark.parametrize("mode", MODES)
+def test_window_attention_strict(ws, heads, nwin, glob, mode, report):
     ops = _ops()
     g = torch.Generator().manual_seed(ws * 100 + heads + glob)
     B, C, N = 2, heads * 32, ws * ws
@@ -183,7 +213,7 @@ def test_window_attention_strict(ws, heads, nwin, glob, report):
     qg = torch.randn(B, N, C, generator=g) if glob else None
     table = torch.randn((2 * ws - 1) ** 2, heads, generator=g) * 0.5
     scale = 32 ** -0.5
-    got = ops.window_attention(dev(qkv), None if qg is None else dev(qg), dev(table), heads, ws, scale)
+    got = ops.window_attention(A(qkv, mode), None if qg is None else A(qg, mode), dev(table), heads, ws, scale)
     win = R.window_partition(qkv, ws).reshape(-1, N, nq, heads, 32).permute(2, 0, 3, 1, 4)      # [nq, B_, heads, N, hd]
     if glob:
         k, v = win[0], win[1]
@@ -195,13 +225,14 @@ def test_window_attention_strict(ws, heads, nwin, glob, report):
     check(report, f"window_attention ws{ws} heads{heads} global={glob}", got, ref)
 
 
-def test_mhsa_strict(report):
+@pytest.mark.parametrize("mode", MODES)
+def test_mhsa_strict(mode, report):
     ops = _ops()
     g = torch.Generator().manual_seed(11)
     B, N, heads = 3, 197, 3
     D = heads * 64
     qkv = torch.randn(B, N, 3 * D, generator=g)
-    got = ops.mhsa(dev(qkv), heads, 64 ** -0.5)
+    got = ops.mhsa(A(qkv, mode), heads, 64 ** -0.5)
     t = qkv.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
     attn = torch.softmax((64 ** -0.5) * (t[0] @ t[1].transpose(-1, -2)), dim=-1)
     ref = (attn @ t[2]).permute(0, 2, 1, 3).reshape(B, N, D)
@@ -231,25 +262,29 @@ STRICT_MEMBERS = ["convnext_tiny_in22k", "resnest50", "gcvit_tiny", "efficientne
 _Z = {}
 
 
-def _strict_logits(key, raws, tag):
+def _strict_logits(key, raws, tag, mode="strict"):
     import vipcup_amd  # noqa: F401
-    from vipcup_amd import pipeline
-    if (key, tag) not in _Z:
-        spec, model = P.gpu_member(key, "strict")
-        assert model.precision == "strict"
-        x = pipeline.decode_jpegs(raws).resized(spec.input_hw, spec.input_hw, dtype=torch.float32)
-        _Z[(key, tag)] = model.logits(x)[:, 0].float().cpu().numpy()
-    return _Z[(key, tag)]
+    from vipcup_amd import ops, pipeline
+    if (key, tag, mode) not in _Z:
+        spec, model = P.gpu_member(key, mode)
+        assert model.precision == mode
+        x = pipeline.decode_jpegs(raws).resized(spec.input_hw, spec.input_hw, dtype=ops.act_dtype(mode))
+        _Z[(key, tag, mode)] = model.logits(x)[:, 0].float().cpu().numpy()
+        if mode == "strict":
+            ops.h2_check(f"{key} ({tag})")                  # no activation left the fp16 range of the packed storage
+    return _Z[(key, tag, mode)]
 
 
-@pytest.mark.parametrize("key", STRICT_MEMBERS)
-def test_member_logit_within_north_star(key, report):
+# every member in the packed mode; the fp32-storage reference arithmetic on three (one per attention / conv / MBConv family)
+@pytest.mark.parametrize("key,mode", [(k, "strict") for k in STRICT_MEMBERS] +
+                         [(k, "f32") for k in ("gcvit_tiny", "efficientnet_v1b4", "vit_tiny_patch16_224")])
+def test_member_logit_within_north_star(key, mode, report):
     n = N_IMG
     raws = [synth_jpeg(i) for i in P.e2e_image_ids(n)]
     z = P.oracle_logits(key, "e2e", raws)               # the CLI test's image set: one oracle pass per member and session
-    zg = _strict_logits(key, raws, "e2e")
+    zg = _strict_logits(key, raws, "e2e", mode)
     dz = np.abs(zg - z)
-    report(f"[strict] {key:22s} {n} images: max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e} logit std {z.std():.2f}")
+    report(f"[{mode}] {key:22s} {n} images: max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e} logit std {z.std():.2f}")
     assert np.isfinite(zg).all()
     assert dz.max() <= P.TOL_NORTH_STAR
 
@@ -265,11 +300,11 @@ def test_member_logit_two_term_gemm(key, report, monkeypatch):
     n = N_IMG
     raws = [synth_jpeg(i) for i in P.e2e_image_ids(n)]
     z = P.oracle_logits(key, "e2e", raws)
-    spec, model = P.gpu_member(key, "strict")
+    spec, model = P.gpu_member(key, "f32")
     x = pipeline.decode_jpegs(raws).resized(spec.input_hw, spec.input_hw, dtype=torch.float32)
     zg = model.logits(x)[:, 0].float().cpu().numpy()
     dz = np.abs(zg - z)
-    report(f"[strict/bf16x2] {key:22s} {n} images: max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e}")
+    report(f"[f32/bf16x2] {key:22s} {n} images: max|dz|={dz.max():.3e} mean|dz|={dz.mean():.3e}")
     assert np.isfinite(zg).all() and dz.max() <= P.TOL_NORTH_STAR
 
 
@@ -297,8 +332,10 @@ def test_ensemble_logit_within_north_star(report):
 
 
 def test_member_inside_batch_256_strict(report):
-    """B = 256 (what bench.py's strict leg times): images 0-7 of the batch against the oracle, two members"""
-    for key in ("resnet_rs50", "efficientnet_v1b4"):
+    """B = 256 (what bench.py's strict leg times): images 0-7 of the batch against the oracle, EVERY member of config 5"""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import zoo
+    for key in zoo.ENSEMBLE8:
         raws = [synth_jpeg(1000 + i) for i in range(256)]
         z = P.oracle_logits(key, "b256_first8", raws[:8])
         zg = _strict_logits(key, raws, "b256")
@@ -314,3 +351,26 @@ def test_precision_mismatch_is_an_error():
     x16 = pipeline.decode_jpegs([synth_jpeg(3)]).resized(224, 224)
     with pytest.raises(_abi.VipError):
         model.predict(x16)
+    x32 = pipeline.decode_jpegs([synth_jpeg(3)]).resized(224, 224, dtype=torch.float32)
+    with pytest.raises(_abi.VipError):
+        model.predict(x32)
+
+
+def test_packed_storage_round_trip_and_range_guard(report):
+    """pack -> unpack keeps 2^-22 relative (2^-25 absolute below 2^-3); a value beyond the fp16 range raises the status word"""
+    import vipcup_amd  # noqa: F401
+    from vipcup_amd import _abi, ops
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(4, 33, 40, generator=g) * torch.logspace(-6, 4, 40)).cuda().contiguous()
+    back = ops.unpack_h2(ops.pack_h2(x))
+    ops.h2_check("round trip")
+    err = (back - x).abs()
+    bound = torch.maximum(x.abs() * 2.0 ** -22, torch.full_like(x, 2.0 ** -25))
+    report(f"[strict-ops] pack/unpack: max rel err {float((err / x.abs().clamp_min(1e-30)).max()):.3e}, worst err / bound {float((err / bound).max()):.3f}")
+    assert bool((err <= bound).all())
+    big = torch.zeros(8, 16).cuda()
+    big[3, 5] = 7.0e4
+    ops.pack_h2(big)
+    with pytest.raises(_abi.VipError):
+        ops.h2_check("overflow probe")
+    ops.h2_check("cleared")                                  # the failed check reset the word

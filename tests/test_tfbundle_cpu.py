@@ -79,8 +79,9 @@ def test_savedmodel_round_trip(tmp_path, block_size):
             assert got[k].dtype == v[k].dtype and got[k].shape == v[k].shape and np.array_equal(got[k], v[k])
     assert T.load_savedmodel_config(str(d)) == cfg
     from vipcup_amd import zoo
-    assert zoo.variant_from_model_config(T.load_savedmodel_config(str(d))) == {"input_hw": (200, 200), "first_strides": 1, "classes": 2,
-                                                                               "head_act": "softmax"}
+    info = zoo.variant_from_model_config(T.load_savedmodel_config(str(d)))
+    assert info == {"input_hw": (200, 200), "stem_strides": 1, "stem_layer": "stem_conv", "n_layers": 4, "classes": 2, "head_act": "softmax"}
+    assert zoo.variant_kwargs(zoo.MEMBERS["resnet_rs50"], info) == {"classes": 2, "first_strides": 1}
 
 
 def test_dtypes_scalars_and_name_based_checkpoints(tmp_path):

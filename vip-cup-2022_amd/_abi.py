@@ -99,6 +99,22 @@ SIGNATURES = {
     "vip_mhsa_fwd_s32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "vip_resize_bicubic_norm_s32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "vip_tta_augment_s32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    # STRICT precision path, packed (hi, lo) fp16 storage: csrc/conv_h2.hip, csrc/strict_ops.hip
+    "vip_pack_h2": (_i, [_vp, _vp, C.c_long, _vp, _vp]),
+    "vip_unpack_h2": (_i, [_vp, _vp, C.c_long, _vp]),
+    "vip_conv2d_nhwc_h2": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _f, _vp, _vp]),
+    "vip_conv2d_kernel_name_h2": (_i, [C.POINTER(ConvDesc), _i, C.c_char_p, _sz]),
+    "vip_dwconv2d_nhwc_h2": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _vp]),
+    "vip_layernorm_h2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "vip_pool2d_nhwc_h2": (_i, [_vp, _vp] + [_i] * 13 + [_vp, _vp]),
+    "vip_global_avgpool_h2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vip_scale_add_act_h2": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "vip_radix_combine_h2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "vip_mul_h2": (_i, [_vp, _vp, _vp, C.c_long] + [_i] * 7 + [_vp, _vp]),
+    "vip_vit_tokens_h2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "vip_gap_ln_dense_h2": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, C.c_long, _i, _vp]),
+    "vip_window_attn_fwd_h2": (_i, [_vp, _vp, _vp, _vp] + [_i] * 7 + [_f, _vp, _vp]),
+    "vip_mhsa_fwd_h2": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "vip_conv2d_kernel_name": (_i, [C.POINTER(ConvDesc), _i, _i, _i, C.c_char_p, _sz]),
     "vip_workspace_bytes": (_sz, [_i, C.POINTER(C.c_int64), _i]),
     "vip_microbench_copy": (_i, [_vp, _vp, _sz, _vp]),

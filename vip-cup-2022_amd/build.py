@@ -30,16 +30,21 @@ def _sources():
                   if f.endswith((".hip", ".cpp")) and (EXPERIMENTS or f not in EXPERIMENT_SOURCES))
 
 
-def _deps_mtime():
+# sources that #include another SOURCE file (one kernel family, two arithmetic modes)
+INCLUDES_SOURCE = {"conv_h2.hip": ["conv_igemm.hip"]}
+
+
+def _deps_mtime(src=None):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     hdrs.append(os.path.join(INCLUDE, "vipcup_hip.h"))
+    hdrs += [os.path.join(CSRC, f) for f in INCLUDES_SOURCE.get(os.path.basename(src or ""), [])]
     return max(os.path.getmtime(h) for h in hdrs)
 
 
 def _compile(src, force):
     obj = os.path.join(OBJ_DIR, os.path.basename(src) + (".exp.o" if EXPERIMENTS else ".o"))
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
-            and os.path.getmtime(obj) >= _deps_mtime()):
+            and os.path.getmtime(obj) >= _deps_mtime(src)):
         return obj
     cmd = [HIPCC, *CXXFLAGS, "-x", "hip", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -142,6 +142,56 @@ union U4H8 {
     f16 e[8];
 };
 
+// ---- packed STRICT storage ("h2", entry points ending in _h2) -----------------------------------------------
+// An activation / weight value v is stored as TWO fp16 terms, hi = rn16(v) and lo = rn16(v - hi): v ~= hi + lo to 2^-22 relative for
+// |v| >= 2^-3 and to 2^-25 absolute below (lo is then an fp16 subnormal; v_mfma_f32_16x16x32_f16 does not flush subnormal inputs -
+// profiles/r04_mfma_f16_subnormal_inputs.log).  Layout: the 8 consecutive channels c0 .. c0+7 (c0 % 8 == 0) of a row are 32 bytes,
+// [hi x 8][lo x 8] - 4 bytes per element like fp32, every 16-byte half IS a v_mfma_f32_16x16x32_f16 operand fragment (8 consecutive k of
+// one pixel), and a channel slice at a multiple of 8 is contiguous.  A contraction is three MFMAs per fragment pair:
+// w x ~= w_lo x_hi + w_hi x_lo + w_hi x_hi (w_lo x_lo <= 2^-22 of the product is dropped).  |v| > 65504 does not fit: producers raise
+// the caller's status word (VIP_H2_OVERFLOW) instead of storing garbage silently.
+constexpr float VIP_H2_MAX = 65504.f;
+// v[8] -> (hi, lo) fragments
+__device__ __forceinline__ void h2_split8(const float (&v)[8], U4H8& hi, U4H8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi.e[j] = (f16)v[j];
+        lo.e[j] = (f16)(v[j] - (float)hi.e[j]);
+    }
+}
+__device__ __forceinline__ void h2_join8(const U4H8& hi, const U4H8& lo, float (&v)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)hi.e[j] + (float)lo.e[j];
+}
+// true when any of the values does not fit the fp16 range (NaN / Inf included)
+__device__ __forceinline__ bool h2_overflows8(const float (&v)[8]) {
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                          fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+    bool bad = !(m <= VIP_H2_MAX);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bad |= (v[j] != v[j]);          // fmaxf drops NaNs
+    return bad;
+}
+// four consecutive logical elements i .. i+3 (i % 4 == 0) of a packed tensor whose element 0 sits at `base` (32-byte aligned)
+__device__ __forceinline__ f32x4 h2_ld4(const void* base, long i) {
+    const char* g = reinterpret_cast<const char*>(base) + (i >> 3) * 32 + ((i >> 2) & 1) * 8;
+    const f16x4 h = *reinterpret_cast<const f16x4*>(g), l = *reinterpret_cast<const f16x4*>(g + 16);
+    return (f32x4){(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+}
+__device__ __forceinline__ void h2_st4(void* base, long i, f32x4 v, int* status) {
+    char* g = reinterpret_cast<char*>(base) + (i >> 3) * 32 + ((i >> 2) & 1) * 8;
+    f16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = (f16)v[j];
+        l[j] = (f16)(v[j] - (float)h[j]);
+    }
+    *reinterpret_cast<f16x4*>(g) = h;
+    *reinterpret_cast<f16x4*>(g + 16) = l;
+    const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if (status && (!(m <= VIP_H2_MAX) || v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3])) *status = VIP_H2_OVERFLOW;
+}
+
 // All-reduce (sum) over aligned groups of `lanes` consecutive lanes (8, 16, 32 or 64).  The first four steps are DPP
 // adds inside a 16-lane row (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: one VALU instruction each, no LDS
 // round trip); only the steps across rows use ds_bpermute (__shfl_xor).  A LayerNorm row is two dependent reductions,

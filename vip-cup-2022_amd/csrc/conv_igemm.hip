@@ -23,6 +23,18 @@
 #include "common.hpp"
 #include <stdlib.h>
 
+// VIP_GEMM_H2 = 1 (conv_h2.hip includes this file a second time): the same kernels for the packed STRICT storage of common.hpp -
+// every operand element is an fp16 (hi, lo) pair, 8 channels = [hi x 8][lo x 8] = two 16-byte MFMA fragments.  Seen as halfs, a packed
+// tensor is an fp16 tensor with twice the channels, so all staging / addressing / tiling below is shared: ConvArgs carries the
+// INPUT side (ldx, cin_off, Cin_g, K, ldw) in halfs (doubled), a 64-half k-chunk is 32 logical k whose eight 16-byte chunks are
+// (hi, lo) x 4 k-groups, and LDS images hold them PERMUTED (h2_pos: the four hi chunks first, then the four lo chunks) so that the
+// fragment reads are the fp16 kernels' own - "k-step 0" reads the hi plane, "k-step 1" the lo plane.  What differs: three MFMAs per
+// fragment pair (w_lo x_hi + w_hi x_hi in k-step 0, w_hi x_lo in k-step 1), direct global fragment loads take chunk 2 lq + plane, and
+// the epilogues (fp32 activations, the weights' power-of-two scale undone, packed residual / output, fp16 range check).
+#ifndef VIP_GEMM_H2
+#define VIP_GEMM_H2 0
+#endif
+
 #ifndef VIP_MFMA_PRIO
 #define VIP_MFMA_PRIO 1
 #endif
@@ -31,6 +43,13 @@
 #endif
 
 namespace {
+
+constexpr bool H2 = VIP_GEMM_H2;
+// LDS position of logical 16-byte chunk c (0..7) of a 64-half row
+__device__ __forceinline__ int h2_pos(int c) { return H2 ? (((c & 1) << 2) | (c >> 1)) : c; }
+// masked lanes of a packed (32-byte) access: base and base + 16 both stay out of range (spans are checked < 0xFFFFFFE0)
+constexpr unsigned OOB2 = 0xFFFFFFE0u;
+constexpr int ESZ = H2 ? 4 : 2;          // bytes per output / residual element
 
 struct ConvArgs {
     const f16* x;
@@ -53,7 +72,39 @@ struct ConvArgs {
     const f16* gate;   // optional per-image input-channel gate [B][2][K] (hi, lo planes of a squeeze-excite scale, folded into the load); pwk only
     int y_lo_off;      // rows kernel: != 0 -> also write fp16(v - fp16(v)) this many halfs after each output (split gate)
     int gate_hw;       // pixels per image (image index of pixel m = m / gate_hw)
+    float out_scale;   // H2: 1 / (power-of-two scale folded into the weights AND the bias), applied to the accumulators
+    int* status;       // H2: device word raised to VIP_H2_OVERFLOW when an output does not fit the fp16 range (may be NULL)
 };
+
+// ---- H2 epilogue core: 8 consecutive channels of one pixel (two accumulator quads) -> activation -> (+ residual) -> post -> packed
+// store.  `off` = byte offset of the channel group in y, `roff` in the residual (OOB2 for masked lanes).
+template <int ACT, bool RES, int POST>      // POST: 0 none, 1 ReLU, 2 run-time a.act_post
+__device__ __forceinline__ void h2_store8(const ConvArgs& a, const f32x4& q0, const f32x4& q1, unsigned off, unsigned roff,
+                                          const __amdgpu_buffer_rsrc_t& rb_res, const __amdgpu_buffer_rsrc_t& rb_y) {
+    float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = vip_act_strict(v[j] * a.out_scale, ACT);
+    if constexpr (RES) {
+        U4H8 rh, rl;
+        rh.u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rb_res, roff, 0, 0));
+        rl.u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rb_res, roff + 16u, 0, 0));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rh.e[j] + (float)rl.e[j];
+    }
+    if constexpr (POST == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    } else if constexpr (POST == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = vip_act_strict(v[j], a.act_post);
+    }
+    U4H8 oh, ol;
+    h2_split8(v, oh, ol);
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh.u), rb_y, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol.u), rb_y, off + 16u, 0, 0);
+    if (a.status && off != OOB2 && h2_overflows8(v)) *a.status = VIP_H2_OVERFLOW;
+}
 
 __device__ __forceinline__ int swz_x(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 __device__ __forceinline__ int swz_w(int row, int chunk) {
@@ -89,6 +140,24 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, f32x4 (&acc)[MT][4],
         const unsigned off = (n < a.Cout_g) ? (unsigned)((ch_glob + n) * 4) : OOB;
         bv[h][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_bias, off, 0, 0));
         bv[h][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_bias, off, 16, 0));
+    }
+    if constexpr (H2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m_base + mt * 16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = n_first + h * 32;
+                const bool ok = (m < a.M) & (n < a.Cout_g);
+                const unsigned off = ok ? (unsigned)(((long)m * a.ldy + a.cout_off + ch_glob + n) * 4) : OOB2;
+                const unsigned roff = (ok && a.res) ? (unsigned)(((long)m * a.ldr + a.res_off + ch_glob + n) * 4) : OOB2;
+                // the bias (pre-multiplied by the weights' scale on the host) joins the accumulators before the scale is undone
+                const f32x4 q0 = acc[mt][h * 2] + bv[h][0], q1 = acc[mt][h * 2 + 1] + bv[h][1];
+                if (a.res) h2_store8<ACT, true, 2>(a, q0, q1, off, roff, rb_res, rb_y);
+                else h2_store8<ACT, false, 2>(a, q0, q1, off, roff, rb_res, rb_y);
+            }
+        }
+        return;
     }
     const bool post_relu = a.act_post == VIP_ACT_RELU;
     const bool post_other = a.act_post != VIP_ACT_NONE && !post_relu;
@@ -232,9 +301,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         char* sa = smem + buf * STAGE_BYTES;
         char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(sa + swz_x(row0 + 32 * i, chunk)) = ra[i];
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(sa + swz_x(row0 + 32 * i, h2_pos(chunk))) = ra[i];
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(sb + swz_w(row0 + 32 * i, chunk)) = rb[i];
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(sb + swz_w(row0 + 32 * i, h2_pos(chunk))) = rb[i];
     };
 
     // ---- MFMA fragment addressing -------------------------------------------------------------
@@ -268,6 +337,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(sb + swz_w(wrow_base + (nt >> 1) * 32 + (nt & 1) * 4, ch));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[mt].u = *reinterpret_cast<const uint4*>(sa + swz_x(xrow_base + mt * 16, ch));
+            if constexpr (H2) {
+                // ks = 0: x hi plane against BOTH weight planes; ks = 1: x lo plane against the weights' hi plane only
+                U4H8 wl[4];
+                if (ks == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) wl[nt].u = *reinterpret_cast<const uint4*>(sb + swz_w(wrow_base + (nt >> 1) * 32 + (nt & 1) * 4, 4 + lq));
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(sb + swz_w(wrow_base + (nt >> 1) * 32 + (nt & 1) * 4, lq));
+                }
+                if (VIP_MFMA_PRIO_TILE) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        if (ks == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt].h, xf[mt].h, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[mt].h, acc[mt][nt], 0, 0, 0);
+                    }
+                if (VIP_MFMA_PRIO_TILE) __builtin_amdgcn_s_setprio(0);
+                continue;
+            }
             if (VIP_MFMA_PRIO_TILE) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -309,6 +399,21 @@ template <int PT, int ACT, bool RES, bool POST_RELU>
 __device__ __forceinline__ void pw_epilogue(const ConvArgs& a, f32x4 (&acc)[PT][4], int m_base, int n_first,
                                             const __amdgpu_buffer_rsrc_t& rb_res, const __amdgpu_buffer_rsrc_t& rb_y) {
     constexpr unsigned OOB = 0xFFFFFFF0u;
+    if constexpr (H2) {
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int m = m_base + p * 16;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = n_first + h * 32;
+                const bool ok = (m < a.M) & (n < a.Cout_g);
+                const unsigned off = ok ? (unsigned)(((long)m * a.ldy + a.cout_off + n) * 4) : OOB2;
+                const unsigned roff = (RES && ok) ? (unsigned)(((long)m * a.ldr + a.res_off + n) * 4) : OOB2;
+                h2_store8<ACT, RES, POST_RELU ? 1 : 0>(a, acc[p][h * 2], acc[p][h * 2 + 1], off, roff, rb_res, rb_y);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int m = m_base + p * 16;
@@ -366,7 +471,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(ConvArgs a, int nb_ch, 
             const unsigned off = ok ? (unsigned)((ch * a.ldw + c * 8) * 2) : OOB;
             const uint4 v = __builtin_bit_cast(uint4, c2 < cpr ? __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0)
                                                                : __builtin_amdgcn_raw_buffer_load_b128(rwl, off, 0, 0));
-            *reinterpret_cast<uint4*>(smem + j * lds_stride + c2 * 16) = v;
+            // H2: logical chunk c of the row -> (64-half k-chunk c >> 3, permuted position of c & 7)
+            *reinterpret_cast<uint4*>(smem + j * lds_stride + (H2 ? ((c2 & ~7) | h2_pos(c2 & 7)) : c2) * 16) = v;
         }
         const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
             (void*)a.bias, 0, a.bias ? (unsigned)(a.bias_elems * 4) : 0u, 0x00020000);
@@ -390,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(ConvArgs a, int nb_ch, 
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
-                const int m = m0 + p * 16 + l15, k = ks * 32 + lq * 8;
+                const int m = m0 + p * 16 + l15, k = H2 ? (ks >> 1) * 64 + lq * 16 + (ks & 1) * 8 : ks * 32 + lq * 8;
                 const bool ok = (m < a.M) & (k < a.K);
                 xf[ks][p].u = __builtin_bit_cast(
                     uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? (unsigned)((m * a.ldx + k) * 2) : OOB, 0, 0));
@@ -419,6 +525,31 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(ConvArgs a, int nb_ch, 
                 U4H8 wf[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + nt * 16 * lds_stride + ks * 64);
+                if constexpr (H2) {
+                    // step ks = 2 c + plane of x: the hi plane (even ks) meets the weights' lo (step ks + 1) and hi (step ks) planes, the lo
+                    // plane (odd ks) the weights' hi plane (step ks - 1)
+                    if ((ks & 1) == 0) {
+                        U4H8 wl[4];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) wl[nt].u = *reinterpret_cast<const uint4*>(ws + nt * 16 * lds_stride + (ks + 1) * 64);
+#pragma unroll
+                        for (int p = 0; p < PT; ++p)
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt) {
+                                acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt].h, xf[ks][p].h, ks == 0 ? bv[nt] : acc[p][nt], 0, 0, 0);
+                                acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[ks][p].h, acc[p][nt], 0, 0, 0);
+                            }
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + nt * 16 * lds_stride + (ks - 1) * 64);
+#pragma unroll
+                        for (int p = 0; p < PT; ++p)
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt)
+                                acc[p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[ks][p].h, acc[p][nt], 0, 0, 0);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int p = 0; p < PT; ++p)
 #pragma unroll
@@ -497,7 +628,7 @@ int launch_pw(const ConvArgs& a, int mode, hipStream_t s) {
 
 template <int PT>
 int launch_pw_k(const ConvArgs& a, int mode, hipStream_t s) {
-    const int ks = (a.K + 31) >> 5;
+    const int ks = H2 ? 2 * ((a.K + 63) >> 6) : (a.K + 31) >> 5;     // H2: whole 64-half chunks (hi and lo planes of 32 logical k)
     switch (ks) {
         case 1: return launch_pw<1, PT>(a, mode, s);
         case 2: return launch_pw<2, PT>(a, mode, s);
@@ -560,14 +691,15 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
         const int t = (j >> 4) & 3, r = j & 15;
         const int ch = n0 + (j & ~63) + (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3);
         w_off[i] = ch < a.Cout_g ? (unsigned)((ch * a.ldw + wc * 8) * 2) : OOB;
-        w_lds[i] = j * ROWB + wc * 16;
+        w_lds[i] = j * ROWB + h2_pos(wc) * 16;
     }
     // activation rows of this lane: pixel m0 + 16 p + l15, k offset lq*8 (+ 32 ks + 64 chunk)
     unsigned x_off[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int m = m0 + p * 16 + l15;
-        x_off[p] = m < a.M ? (unsigned)((m * a.ldx + lq * 8) * 2) : 0xFFFF0000u;   // + k bytes stays out of range
+        // H2: the lane's k-group is the 32-byte (hi, lo) pair lq of the 64-half chunk; plane `ks` is 16 bytes further
+        x_off[p] = m < a.M ? (unsigned)((m * a.ldx + lq * (H2 ? 16 : 8)) * 2) : 0xFFFF0000u;   // + k bytes stays out of range
     }
     // squeeze-excite gate folded into the activation operand: x[m, k] * (hi + lo)[image(m), k] as fma(x, hi, x * lo) in
     // packed fp16 - the product is rounded once, per element; the gate itself carries ~22 bits (see se_gate.hip)
@@ -595,11 +727,11 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
     U4H8 xf[2][PT], gq[GATED ? 2 : 1][GATED ? PT : 1];      // gq: the gate planes (hi, lo) of ONE k-step
     auto load_x = [&](int kc, int ks) {
         // weights of the K tail are zero in LDS, but 0 * (Inf/NaN garbage of the next row) is NaN: mask the lanes
-        const bool ok = kc * 64 + ks * 32 + lq * 8 < a.K;
+        const bool ok = kc * 64 + (H2 ? lq * 16 + ks * 8 : ks * 32 + lq * 8) < a.K;
 #pragma unroll
         for (int p = 0; p < PT; ++p)
             xf[ks][p].u = __builtin_bit_cast(
-                uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + kc * 128 + ks * 64 : OOB, 0, 0));
+                uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + kc * 128 + ks * (H2 ? 16 : 64) : OOB, 0, 0));
     };
     // Gate fragments run one k-step ahead of their use in ONE register set (a second prefetched set does not fit next to
     // the accumulators): gate_x(ks) folds them into xf[ks] - fma(x, hi, x * lo) in packed fp16 - and the set is
@@ -651,6 +783,28 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             U4H8 wf[4];
+            if constexpr (H2) {
+                // ks = 0: the x hi fragments against the weights' lo plane (ws + 64) and hi plane (ws); ks = 1: x lo against the hi
+                // plane (ws - 64: the lambda's ks * 64 points at the lo plane)
+                const char* wh = ws - ks * 64;
+                U4H8 wl[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(wh + (g * 64 + nt * 16) * ROWB);
+                if (ks == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) wl[nt].u = *reinterpret_cast<const uint4*>(wh + 64 + (g * 64 + nt * 16) * ROWB);
+                }
+                if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) {
+                        if (ks == 0) acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt].h, xf[0][p].h, acc[g][p][nt], 0, 0, 0);
+                        acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[ks][p].h, acc[g][p][nt], 0, 0, 0);
+                    }
+                if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+                continue;
+            }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + (g * 64 + nt * 16) * ROWB);
             if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
@@ -936,7 +1090,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
         const int t = (j >> 4) & 3, r = j & 15;
         const int ch = nblk + (j & ~63) + (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3);
         w_off[i] = ch < a.Cout_g ? (unsigned)((ch * a.ldw + wc * 8) * 2) : OOB;
-        w_lds[i] = j * ROWB + wc * 16;
+        w_lds[i] = j * ROWB + h2_pos(wc) * 16;
     }
     // Activation staging: the block's 256 pixels x 64 k of a chunk are fetched in FULL 128-byte lines (8 consecutive
     // lanes = one pixel row's 64 halfs, 8 rows per wave-instruction), parked in four 64-pixel LDS images and read back
@@ -1009,7 +1163,7 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
     auto store_x = [&]() {
 #pragma unroll
         for (int i = 0; i < X_IT; ++i) {
-            *reinterpret_cast<uint4*>(ximg + (xr + XROWS * i) * ROWB + xc * 16) = xst[i].u;   // image r/64, row r%64
+            *reinterpret_cast<uint4*>(ximg + (xr + XROWS * i) * ROWB + h2_pos(xc) * 16) = xst[i].u;   // image r/64, row r%64
         }
     };
     const char* xs = ximg + wm * XS;
@@ -1043,6 +1197,26 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             U4H8 wf[4];
+            if constexpr (H2) {     // as in pwk_direct_kernel: xf is the hi (ks = 0) / lo (ks = 1) plane of x
+                const char* wh = ws - ks * 64;
+                U4H8 wl[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(wh + (g * 64 + nt * 16) * ROWB);
+                if (ks == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) wl[nt].u = *reinterpret_cast<const uint4*>(wh + 64 + (g * 64 + nt * 16) * ROWB);
+                }
+                if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) {
+                        if (ks == 0) acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt].h, xf[p].h, acc[g][p][nt], 0, 0, 0);
+                        acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xf[p].h, acc[g][p][nt], 0, 0, 0);
+                    }
+                if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+                continue;
+            }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + (g * 64 + nt * 16) * ROWB);
             if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
@@ -1180,17 +1354,18 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(ConvArgs a) {
         (void*)a.w, 0, (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.x + a.cin_off), 0, (unsigned)min((long)0xFFFFFFF0L, a.x_span_bytes - 2L * a.cin_off), 0x00020000);
-    const unsigned w_off = (n0 + l15 < a.Cout_g) ? (unsigned)(((n0 + l15) * a.ldw + lq * 8) * 2) : 0xFFFF0000u;
+    // H2: k-step u = 2 c + plane of the 64-half chunk c; the lane's k-group is the 32-byte (hi, lo) pair lq of the chunk
+    const unsigned w_off = (n0 + l15 < a.Cout_g) ? (unsigned)(((n0 + l15) * a.ldw + lq * (H2 ? 16 : 8)) * 2) : 0xFFFF0000u;
     unsigned x_off[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int m = m0 + p * 16 + l15;
-        x_off[p] = m < a.M ? (unsigned)((m * a.ldx + lq * 8) * 2) : 0xFFFF0000u;
+        x_off[p] = m < a.M ? (unsigned)((m * a.ldx + lq * (H2 ? 16 : 8)) * 2) : 0xFFFF0000u;
     }
     f32x4 acc[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nks = (a.K + 31) >> 5;
+    const int nks = H2 ? 2 * ((a.K + 63) >> 6) : (a.K + 31) >> 5;
     const int per = ((nks + 3) / 4 + 3) & ~3;                // k-steps per K quarter, multiple of the unroll
     const int ks_lo = kq * per, ks_hi = min(nks, ks_lo + per);
     if (m0 < a.M) {
@@ -1198,11 +1373,24 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(ConvArgs a) {
             U4H8 wf[4], xf[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const bool ok = (ks0 + u < ks_hi) & ((ks0 + u) * 32 + lq * 8 < a.K);
-                wf[u].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? w_off + (ks0 + u) * 64 : OOB, 0, 0));
+                const int kst = ks0 + u;
+                const bool ok = (kst < ks_hi) & ((H2 ? (kst >> 1) * 64 + lq * 16 + (kst & 1) * 8 : kst * 32 + lq * 8) < a.K);
+                const unsigned kb = H2 ? (unsigned)((kst >> 1) * 128 + (kst & 1) * 16) : (unsigned)(kst * 64);
+                wf[u].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rw, ok ? w_off + kb : OOB, 0, 0));
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-                    xf[u][p].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + (ks0 + u) * 64 : OOB, 0, 0));
+                    xf[u][p].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? x_off[p] + kb : OOB, 0, 0));
+            }
+            if constexpr (H2) {     // (ks0, per: multiples of 4, so u = 0 / 2 are hi planes and u + 1 their lo planes)
+#pragma unroll
+                for (int u = 0; u < 4; u += 2)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u + 1].h, xf[u][p].h, acc[p], 0, 0, 0);
+                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u].h, xf[u + 1][p].h, acc[p], 0, 0, 0);
+                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u].h, xf[u][p].h, acc[p], 0, 0, 0);
+                    }
+                continue;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -1243,6 +1431,15 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(ConvArgs a) {
             const int n = n0 + lq * 4 + r;
             v[r] = acc[p][r] + red[0][mw][p * 4 + r][lane] + red[1][mw][p * 4 + r][lane] + red[2][mw][p * 4 + r][lane] +
                    ((a.bias && n < a.Cout_g) ? a.bias[n] : 0.f);
+        }
+        if constexpr (H2) {     // 4 consecutive channels of a packed row (Cout % 8 == 0, so the quad is whole or absent)
+            if (n0 + lq * 4 < a.Cout_g) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = vip_act_strict(v[r] * a.out_scale, a.act_pre);
+                h2_st4(a.y, (long)m * a.ldy + a.cout_off + n0 + lq * 4, o, a.status);
+            }
+            continue;
         }
         f16* dst = a.y + (long)m * a.ldy + a.cout_off + n0 + lq * 4;
 #pragma unroll
@@ -1301,7 +1498,8 @@ static thread_local const char* g_pick = "";
     } while (0)
 
 static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void* w, const float* bias, const void* residual, void* y,
-                       const vip_conv_desc* d, void* stream, const void* w_lo = nullptr, bool x_split = false) {
+                       const vip_conv_desc* d, void* stream, const void* w_lo = nullptr, bool x_split = false, float out_scale = 1.f,
+                       int* status = nullptr) {
     VIP_REQUIRE(x && w && y && d, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_f16: null pointer");
     VIP_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 &&
                     d->sh > 0 && d->sw > 0 && d->Ho > 0 && d->Wo > 0 && d->groups > 0 && d->pt >= 0 && d->pl >= 0,
@@ -1314,8 +1512,11 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
     VIP_REQUIRE(d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldw % 8 == 0 && d->cin_off % 8 == 0 &&
                     d->cout_off % 8 == 0 && (!residual || (d->ldr % 8 == 0 && d->res_off % 8 == 0)),
                 VIP_ERR_ALIGNMENT, "vip_conv2d_nhwc_f16: strides/offsets must be multiples of 8 halfs");
-    VIP_REQUIRE(d->ldx >= d->cin_off + d->Cin && d->ldy >= d->cout_off + d->Cout && d->ldw >= d->kh * d->kw * cin_g,
+    constexpr int IN = H2 ? 2 : 1;       // halfs per input element (H2: an (hi, lo) pair)
+    VIP_REQUIRE(d->ldx >= d->cin_off + d->Cin && d->ldy >= d->cout_off + d->Cout && d->ldw >= IN * d->kh * d->kw * cin_g,
                 VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_f16: leading dimension smaller than the channel extent");
+    VIP_REQUIRE(!H2 || (d->ldw % 16 == 0 && !gate && !w_lo && !y_lo_off && !x_split), VIP_ERR_BAD_ARG,
+                "vip_conv2d_nhwc_h2: ldw must be a multiple of 16 halfs; no gate / split variants");
     VIP_REQUIRE((unsigned)d->act_pre <= 4u && (unsigned)d->act_post <= 4u, VIP_ERR_BAD_ARG,
                 "vip_conv2d_nhwc_f16: unknown activation code");
     // the caller's Ho/Wo must not read past what padding+kernel imply on the top/left; bottom/right
@@ -1326,16 +1527,19 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
     ConvArgs a;
     a.x = (const f16*)x; a.w = (const f16*)w; a.bias = bias; a.res = (const f16*)residual; a.y = (f16*)y;
     a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
-    a.Cin_g = cin_g; a.Cout_g = cout_g;
+    // the INPUT side in halfs (H2: twice the logical channels - see the head of this file), the output side in logical channels
+    a.Cin_g = cin_g * IN; a.Cout_g = cout_g;
     a.kh = d->kh; a.kw = d->kw; a.sh = d->sh; a.sw = d->sw; a.pt = d->pt; a.pl = d->pl;
-    a.ldx = d->ldx; a.ldy = d->ldy; a.ldr = d->ldr; a.ldw = d->ldw;
-    a.cin_off = d->cin_off; a.cout_off = d->cout_off; a.res_off = d->res_off;
-    a.M = (int)M; a.K = d->kh * d->kw * cin_g;
-    a.x_span_bytes = 2L * d->B * d->H * d->W * d->ldx;
-    a.y_span_bytes = 2L * M * d->ldy;
-    a.res_span_bytes = 2L * M * d->ldr;
+    a.ldx = d->ldx * IN; a.ldy = d->ldy; a.ldr = d->ldr; a.ldw = d->ldw;
+    a.cin_off = d->cin_off * IN; a.cout_off = d->cout_off; a.res_off = d->res_off;
+    a.M = (int)M; a.K = d->kh * d->kw * cin_g * IN;
+    a.x_span_bytes = 2L * IN * d->B * d->H * d->W * d->ldx;
+    a.y_span_bytes = (long)ESZ * M * d->ldy;
+    a.res_span_bytes = (long)ESZ * M * d->ldr;
     a.bias_elems = d->Cout;
-    VIP_REQUIRE(a.y_span_bytes < 0xFFFFFFF0L && a.res_span_bytes < 0xFFFFFFF0L, VIP_ERR_UNSUPPORTED,
+    a.out_scale = out_scale;
+    a.status = status;
+    VIP_REQUIRE(a.y_span_bytes < 0xFFFFFFE0L && a.res_span_bytes < 0xFFFFFFE0L, VIP_ERR_UNSUPPORTED,
                 "vip_conv2d_nhwc_f16: output or residual tensor exceeds the 4 GiB buffer-addressing range");
     VIP_REQUIRE(a.x_span_bytes < 0xFFFFFFF0L && 2L * d->Cout * d->ldw < 0xFFFFFFF0L, VIP_ERR_UNSUPPORTED,
                 "vip_conv2d_nhwc_f16: input or weight tensor exceeds the 4 GiB buffer-addressing range");
@@ -1420,6 +1624,27 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
     VIP_PICK("conv_igemm_kernel", short_k ? (launch<64, 128>(a, d->groups, s)) : (launch<128, 128>(a, d->groups, s)));
 }
 
+#if VIP_GEMM_H2
+/* Conv2D / Dense on the packed STRICT storage (include/vipcup_hip.h): x, residual, y packed [.., C] (4 bytes per element), w packed
+ * rows [Cout][ldw halfs] = per 8 k: [hi x 8][lo x 8] of (W * w_scale), bias = b * w_scale (fp32), out_scale = 1 / w_scale. */
+extern "C" int vip_conv2d_nhwc_h2(const void* x, const void* w, const float* bias, const void* residual, void* y, const vip_conv_desc* d,
+                                  float out_scale, int* status, void* stream) {
+    VIP_REQUIRE(out_scale > 0.f, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_h2: out_scale must be positive");
+    return conv2d_impl(x, nullptr, 0, w, bias, residual, y, d, stream, nullptr, false, out_scale, status);
+}
+
+extern "C" int vip_conv2d_kernel_name_h2(const vip_conv_desc* d, int has_residual, char* name, size_t cap) {
+    VIP_REQUIRE(d && name && cap > 0, VIP_ERR_BAD_ARG, "vip_conv2d_kernel_name_h2: null pointer");
+    static const char dummy[16] = {0};     // non-null stand-ins: nothing is dereferenced or launched in a dry run
+    g_dry = true;
+    g_pick = "";
+    const int st = conv2d_impl(dummy, nullptr, 0, dummy, nullptr, has_residual ? dummy : nullptr, const_cast<char*>(dummy), d, nullptr);
+    g_dry = false;
+    if (st != VIP_OK) return st;
+    snprintf(name, cap, "%s", g_pick);
+    return VIP_OK;
+}
+#else
 extern "C" int vip_conv2d_nhwc_f16(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                    const vip_conv_desc* d, void* stream) {
     return conv2d_impl(x, nullptr, 0, w, bias, residual, y, d, stream);
@@ -1483,3 +1708,4 @@ extern "C" int vip_gemm_split2_f16(const void* A, const void* W, const float* bi
     d.res_off = 0; d.ldw = ldw; d.act_pre = act; d.act_post = VIP_ACT_NONE;
     return conv2d_impl(A, nullptr, N, W, bias, nullptr, C, &d, stream, nullptr, true);
 }
+#endif  // VIP_GEMM_H2

@@ -89,7 +89,10 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
     for (int i = 0; i < 2; ++i) {
         const int rg = wave * 2 + i;               // 8-row group 0..15
         const int j = rg * 8 + (lane >> 3);
-        chk[i] = pc ^ ((j >> 1) & 7);
+        // physical chunk pc of LDS row j holds logical POSITION pc ^ key(j); H2: position L is source chunk ((L & 3) << 1) | (L >> 2)
+        // (the inverse of h2_pos: the four hi chunks of the 64-half row first, then the four lo chunks)
+        const int lpos = pc ^ ((j >> 1) & 7);
+        chk[i] = H2 ? (((lpos & 3) << 1) | (lpos >> 2)) : lpos;
         dma_lds[i] = rg * 1024;
         const int jj = j & 63, t = (jj >> 4) & 3, r = jj & 15;
         rowA[i] = (j >> 6) * 128 + (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3);     // + 64 g
@@ -178,11 +181,25 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
     do {                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
         __builtin_amdgcn_s_setprio(1);                                                                                  \
+        if constexpr (H2) {     /* [0] = hi plane, [1] = lo plane: w_lo x_hi + w_hi x_hi + w_hi x_lo */                         \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                            \
+                _Pragma("unroll") for (int pp = 0; pp < 2; ++pp) {                                                      \
+                    acc[G][P0 + pp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[nt][1].h, BF[pp][0].h,              \
+                                                                                 acc[G][P0 + pp][nt], 0, 0, 0);        \
+                    acc[G][P0 + pp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[nt][0].h, BF[pp][0].h,              \
+                                                                                 acc[G][P0 + pp][nt], 0, 0, 0);        \
+                }                                                                                                       \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                            \
+                _Pragma("unroll") for (int pp = 0; pp < 2; ++pp)                                                        \
+                    acc[G][P0 + pp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[nt][0].h, BF[pp][1].h,              \
+                                                                                 acc[G][P0 + pp][nt], 0, 0, 0);        \
+        } else {                                                                                                        \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                            \
                 _Pragma("unroll") for (int pp = 0; pp < 2; ++pp)                                                        \
                     acc[G][P0 + pp][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[nt][ks].h, BF[pp][ks].h,            \
                                                                                  acc[G][P0 + pp][nt], 0, 0, 0);        \
+        }                                                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                                  \
     } while (0)
 

@@ -265,8 +265,9 @@ def score_files(jpegs_for: Callable[[int, int], List[bytes]], n_images: int, mem
 
 
 def member_dtype(model) -> torch.dtype:
-    """activation dtype a member was built for: fp32 for ``precision == "strict"`` (zoo.construct), fp16 otherwise"""
-    return torch.float32 if getattr(model, "precision", "fast") == "strict" else torch.float16
+    """activation dtype a member was built for (zoo.construct): packed pairs for "strict", fp32 for "f32", fp16 otherwise"""
+    from . import ops
+    return ops.act_dtype(getattr(model, "precision", "fast"))
 
 
 def input_key(spec, model):

@@ -46,7 +46,7 @@ def main(argv=None):
                     help="how N > 1 ranks split the (member, image-shard) grid: images = every rank all members on its image shard "
                          "(MirroredStrategy's split, utils/device.py:7); members = rank r owns members r mod N and scores every "
                          "image (one model per GPU); hybrid = LPT packing by measured ms/image.  One all-gather in every mode.")
-    ap.add_argument("--precision", default=None, choices=["fast", "strict"],
+    ap.add_argument("--precision", default=None, choices=["fast", "strict", "f32"],
                     help="fast (default; env VIP_PRECISION): fp16 storage, the throughput path - member logits at the fp16 storage floor "
                          "(7e-4 ... 8e-3 vs an fp32 run).  strict: fp32 storage and fp32 matrix arithmetic, what the reference's "
                          "TensorFlow run computes in (main.py:107-109): every member's logit within 1e-3 of it, ~3.5x slower.")

@@ -52,7 +52,7 @@ def _chk32(t: torch.Tensor, name: str):
 
 
 def _is32(t: torch.Tensor, name: str) -> bool:
-    """True: ``t`` is an fp32 activation (STRICT path, the ``_s32`` entry points); False: fp16 (fast path).  Raises otherwise."""
+    """True: ``t`` is an fp32 activation (the ``_s32`` entry points); False: fp16 (fast path).  Raises otherwise."""
     if t.dtype == torch.float32:
         _chk32(t, name)
         return True
@@ -60,14 +60,91 @@ def _is32(t: torch.Tensor, name: str) -> bool:
     return False
 
 
+# The packed STRICT storage (csrc/common.hpp, include/vipcup_hip.h "_h2"): 4 bytes per element - an fp16 (hi, lo) pair, 8 channels =
+# [hi x 8][lo x 8].  Its carrier on the torch side is an int32 tensor of the LOGICAL shape ([B, H, W, C], C % 8 == 0): torch only
+# allocates, reshapes and slices it (on whole 8-channel groups); no torch arithmetic ever touches the bits.
+PACKED = torch.int32
+
+
+def _chkp(t: torch.Tensor, name: str):
+    if t.dtype != PACKED or not t.is_cuda or not t.is_contiguous() or t.shape[-1] % 8:
+        raise _abi.VipError(f"{name}: expected a contiguous CUDA packed-strict (int32 carrier) tensor with C % 8 == 0, got {t.dtype} "
+                            f"{t.device} {tuple(t.shape)} contiguous={t.is_contiguous()}")
+
+
+def _kind(t: torch.Tensor, name: str) -> str:
+    """storage of an activation tensor: "f16" (fast path), "s32" (fp32 storage) or "h2" (packed strict); raises otherwise"""
+    if t.dtype == PACKED:
+        _chkp(t, name)
+        return "h2"
+    return "s32" if _is32(t, name) else "f16"
+
+
+def _chk_kind(t: torch.Tensor, kind: str, name: str):
+    {"f16": _chk16, "s32": _chk32, "h2": _chkp}[kind](t, name)
+
+
+_H2_STATUS: dict = {}
+
+
+def h2_status(device=None) -> torch.Tensor:
+    """the device word packed-strict producers raise when a value does not fit the fp16 range (VIP_H2_OVERFLOW); one per device"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _H2_STATUS:
+        _H2_STATUS[key] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    return _H2_STATUS[key]
+
+
+def h2_check(what: str = "strict forward pass", device=None):
+    """Synchronising check of the status word; raises (and clears the word) when a packed-strict producer met a value beyond the fp16
+    range - the caller then reruns in ``precision("f32")`` (fp32 storage)."""
+    st = h2_status(device)
+    if int(st.item()) != 0:
+        st.zero_()
+        raise _abi.VipError(f"{what}: an activation left the fp16 range of the packed strict storage (|v| > 65504 or NaN); "
+                            "use --precision f32 (fp32 storage) for this model")
+
+
+def _strict_call(base: str, kind: str, *args, status: bool = True):
+    """``vip_<base>_s32(*args, stream)`` or ``vip_<base>_h2(*args, status, stream)``"""
+    fn = f"vip_{base}_{kind}"
+    extra = [_p(h2_status())] if (kind == "h2" and status) else []
+    st = getattr(_abi.lib(), fn)(*args, *extra, _stream())
+    _abi.check(st, fn)
+
+
+def pack_h2(x: torch.Tensor) -> torch.Tensor:
+    """fp32 ``[..., C]`` (C % 8 == 0) -> packed strict tensor of the same logical shape"""
+    _chk32(x, "pack_h2.x")
+    assert x.shape[-1] % 8 == 0, x.shape
+    out = torch.empty(x.shape, dtype=PACKED, device=x.device)
+    st = _abi.lib().vip_pack_h2(_p(x), _p(out), x.numel(), _p(h2_status()), _stream())
+    _abi.check(st, "vip_pack_h2")
+    return out
+
+
+def unpack_h2(x: torch.Tensor) -> torch.Tensor:
+    """packed strict tensor -> fp32 of the same logical shape (hi + lo)"""
+    _chkp(x, "unpack_h2.x")
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    st = _abi.lib().vip_unpack_h2(_p(x), _p(out), x.numel(), _stream())
+    _abi.check(st, "vip_unpack_h2")
+    return out
+
+
 # ---- precision mode ------------------------------------------------------------------------------------------------------------
 # "fast":   fp16 storage of activations and weights, fp32 accumulate (the throughput path; member logits at the fp16 storage floor).
-# "strict": fp32 storage, fp32 matrix arithmetic (v_mfma_f32_32x32x2_f32 or three-term bf16 splits), fp32 activations - what the reference computes in
-#           (main.py:107-109, TensorFlow fp32) and the mode in which BASELINE.json's |dz| <= 1e-3 holds for every member.
-# The mode is a property of the WEIGHTS a model was constructed with (``precision("strict")`` around the constructor) and of the
+# "strict": the mode in which BASELINE.json's |dz| <= 1e-3 holds for every member (the reference computes in fp32: main.py:107-109).
+#           Since round 4: PACKED storage - every activation / weight value is an fp16 (hi, lo) pair (22 significant bits, 4 bytes),
+#           contractions are three v_mfma_f32_16x16x32_f16 per fragment pair with fp32 accumulation (the fast path's own GEMM kernels
+#           instantiated for this storage: csrc/conv_h2.hip), everything else fp32 arithmetic on the joined value.
+# "f32":    fp32 storage, fp32 matrix arithmetic (v_mfma_f32_32x32x2_f32 or three-term bf16 splits) - round 3's strict mode, kept as
+#           the reference arithmetic and as the fallback when an activation leaves the fp16 range (h2_check).
+# The mode is a property of the WEIGHTS a model was constructed with (``precision(mode)`` around the constructor) and of the
 # activation dtype it is fed: every operator below dispatches on ``x.dtype``.
 PRECISION = os.environ.get("VIP_PRECISION", "fast")
-PRECISIONS = ("fast", "strict")
+PRECISIONS = ("fast", "strict", "f32")
 
 
 class precision:
@@ -89,9 +166,19 @@ class precision:
         return False
 
 
+def to_act(t: torch.Tensor, device="cuda", dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """a host fp32 tensor -> the activation storage ``dtype`` (default: the current precision mode's) on ``device``: a cast for fp16 /
+    fp32, the (hi, lo) split for the packed strict storage (last axis % 8 == 0).  For parameters that enter the graph as activations
+    (ViT class token / position embeddings)."""
+    dtype = dtype or act_dtype()
+    if dtype == PACKED:
+        return pack_h2(t.detach().to(device=device, dtype=torch.float32).contiguous())
+    return t.detach().to(device=device, dtype=dtype).contiguous()
+
+
 def act_dtype(mode: Optional[str] = None) -> torch.dtype:
     """storage type of activations in a precision mode"""
-    return torch.float32 if (mode or PRECISION) == "strict" else torch.float16
+    return {"fast": torch.float16, "strict": PACKED, "f32": torch.float32}[mode or PRECISION]
 
 
 @dataclass
@@ -109,7 +196,8 @@ class ConvWeight:
     err: Optional[torch.Tensor] = None   # fp32 [cout, ldw]: (fp32 weight - stored fp16 weight), kept only until calibrate()
     w_lo: Optional[torch.Tensor] = None  # fp16 [cout, ldw]: fp16(W32 - w) for the two-term-weight kernel (see make_conv_weight)
     exact: Optional["ConvWeight"] = None  # calibration only (exact_weights()): [w | fp16(W32 - w)] along K, the uncorrected bias
-    w_bf3: Optional[torch.Tensor] = None  # strict: the fp32 weights as three bf16 planes [3, cout, ldwp] (w = p0 + p1 + p2 exactly)
+    w_bf3: Optional[torch.Tensor] = None  # f32 mode: the fp32 weights as three bf16 planes [3, cout, ldwp] (w = p0 + p1 + p2 exactly)
+    h2_scale: float = 0.0                 # packed strict mode (> 0): ``w`` holds fp16 (hi, lo) pairs of W * h2_scale, ``bias`` = b * h2_scale
 
     @property
     def cin(self):
@@ -117,8 +205,13 @@ class ConvWeight:
 
     @property
     def strict(self):
-        """fp32 weights (constructed under ``precision("strict")``)"""
+        """fp32 weights (constructed under ``precision("f32")``)"""
         return self.w.dtype == torch.float32
+
+    @property
+    def kind(self):
+        """the activation storage this weight was built for: "f16" | "s32" | "h2" """
+        return "h2" if self.h2_scale > 0 else ("s32" if self.strict else "f16")
 
     @property
     def ldw(self):
@@ -261,6 +354,26 @@ def split_bf16x3(w_rows: torch.Tensor) -> torch.Tensor:
     return planes.contiguous()
 
 
+def split_h2_weights(w_rows: torch.Tensor):
+    """fp32 ``[rows, K]`` (K % 8 == 0) -> (fp16 ``[rows, 2 K]``, scale): per 8 consecutive k the 16 halfs ``[hi x 8][lo x 8]`` of
+    ``W * scale``, hi = rn16(W scale), lo = rn16(W scale - hi) - the weight operand of vip_conv2d_nhwc_h2.  ``scale`` is the power of
+    two that puts the layer's largest |W| in [4096, 8192): every lo term of a weight within 2^-15 of that maximum is then an fp16
+    NORMAL (22 significant bits for hi + lo), nothing overflows, and the kernel undoes it exactly on the fp32 accumulators."""
+    w = w_rows.detach().to(torch.float32)
+    rows, K = w.shape
+    assert K % 8 == 0, K
+    mx = float(w.abs().max()) if w.numel() else 0.0
+    scale = 1.0
+    if mx > 0.0 and mx == mx and mx != float("inf"):
+        import math
+        scale = 2.0 ** math.floor(math.log2(8191.0 / mx))
+    ws = w * scale
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.to(torch.float32)).to(torch.float16)
+    packed = torch.stack([hi.reshape(rows, K // 8, 8), lo.reshape(rows, K // 8, 8)], 2).reshape(rows, 2 * K)
+    return packed.contiguous(), float(scale)
+
+
 # STRICT GEMM arithmetic: "bf16x3" (default) = three-term bf16 splits, six bf16 MFMAs per block (vip_conv2d_nhwc_s32x); "f32" = the
 # f32-input MFMA (vip_conv2d_nhwc_s32), 2.7x lower matrix rate.  Same results to f32 round-off (tests/test_gpu_strict.py runs both).
 # "bf16x2" = two-term splits, three MFMAs per block (vip_conv2d_nhwc_s32x2): 2^-17 of each product dropped - NOT f32 quality, 64x finer
@@ -300,9 +413,17 @@ def make_conv_weight(kernel_hwio: torch.Tensor, bias: Optional[torch.Tensor], gr
         if b is not None:
             b = torch.cat([b, b.new_zeros(pad_cout_to - cout)])
         cout = pad_cout_to
-    if PRECISION == "strict":          # fp32 weights as they are: nothing to round, nothing to calibrate
+    if PRECISION == "strict":          # packed (hi, lo) fp16 pairs of W * 2^s: nothing to calibrate
+        if cin_g % 8 or (cout // groups) % 8:
+            raise _abi.VipError(f"make_conv_weight(strict): Cin_g={cin_g} / Cout_g={cout // groups} must be multiples of 8 "
+                                "(pad_cin_to / pad_cout_to)")
+        w32 = k.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin_g).contiguous()
+        wp, scale = split_h2_weights(w32)
+        return ConvWeight(w=wp.to(device), bias=None if b is None else (b * scale).to(device).contiguous(), kh=kh, kw=kw, cin_g=cin_g,
+                          cout=cout, groups=groups, alg_cin_g=alg_cin_g, h2_scale=scale)
+    if PRECISION == "f32":             # fp32 weights as they are: nothing to round, nothing to calibrate
         if cin_g % 4 or (cout // groups) % 4:
-            raise _abi.VipError(f"make_conv_weight(strict): Cin_g={cin_g} / Cout_g={cout // groups} must be multiples of 4 "
+            raise _abi.VipError(f"make_conv_weight(f32): Cin_g={cin_g} / Cout_g={cout // groups} must be multiples of 4 "
                                 "(pad_cin_to / pad_cout_to)")
         w32 = k.permute(3, 0, 1, 2).reshape(cout, kh * kw * cin_g).contiguous()
         return ConvWeight(w=w32.to(device), bias=None if b is None else b.to(device).contiguous(), kh=kh, kw=kw, cin_g=cin_g,
@@ -357,10 +478,13 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
     either way.
     ``x`` may carry more channels than the weight consumes (``cin_off`` selects the slice); ``out`` may
     be a wider tensor written at ``cout_off`` (concat-free channel splits / joins)."""
-    if _is32(x, "conv2d.x"):
+    kind = _kind(x, "conv2d.x")
+    if kind != cw.kind:
+        raise _abi.VipError(f"conv2d: {kind} activations with {cw.kind} weights - build the model and its input in the same precision")
+    if kind == "s32":
         return _conv2d_s32(x, cw, stride, pad, act, act_post, residual, out, cin_off, cout_off, gate)
-    if cw.strict:
-        raise _abi.VipError("conv2d: fp16 activations with strict (fp32) weights - build the model and its input in the same precision")
+    if kind == "h2":
+        return _conv2d_h2(x, cw, stride, pad, act, act_post, residual, out, cin_off, cout_off, gate)
     if gate is not None and _UNFUSED:
         assert gate.shape == (x.shape[0], 2, cw.cin) and x.shape[3] == cw.cin and cin_off == 0
         x, gate = scale_add_act(x, gate, None, None), None
@@ -416,10 +540,62 @@ def conv2d(x: torch.Tensor, cw: ConvWeight, stride=1, pad=(0, 0, 0, 0), act=None
     return out
 
 
+def conv_kernel_name_h2(d: "_abi.ConvDesc", has_residual: bool) -> Optional[str]:
+    """the kernel vip_conv2d_nhwc_h2 launches for this descriptor (a dry run of the C dispatcher)"""
+    buf = C.create_string_buffer(64)
+    st = _abi.lib().vip_conv2d_kernel_name_h2(C.byref(d), int(has_residual), buf, 64)
+    return buf.value.decode() if st == 0 else None
+
+
+_H2_SPAN_MAX = 0xFFFFFFE0       # the C kernels address every tensor through 32-bit buffer offsets
+
+
+def _conv2d_h2(x, cw: ConvWeight, stride, pad, act, act_post, residual, out, cin_off, cout_off, gate):
+    """packed-STRICT conv2d: packed x / residual / out, vip_conv2d_nhwc_h2; a packed gate [B, Cin] is multiplied in first.  Tensors
+    beyond the 4 GiB the kernels can address are processed in batch slices (images are independent)."""
+    if gate is not None:
+        assert gate.shape == (x.shape[0], cw.cin) and x.shape[3] == cw.cin and cin_off == 0, (gate.shape, x.shape, cw.cin)
+        x = scale_add_act(x, gate, None, None)
+    B, H, W, ldx = x.shape
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    pt, pb, pl, pr = pad
+    Ho = (H + pt + pb - cw.kh) // sh + 1
+    Wo = (W + pl + pr - cw.kw) // sw + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, cw.cout), dtype=PACKED, device=x.device)
+    else:
+        _chkp(out, "conv2d.out")
+        assert out.shape[:3] == (B, Ho, Wo), (out.shape, (B, Ho, Wo))
+    if residual is not None:
+        _chkp(residual, "conv2d.residual")
+        assert residual.shape[:3] == (B, Ho, Wo) and residual.shape[3] >= cw.cout
+    per_img = 4 * max(H * W * ldx, Ho * Wo * out.shape[3], 0 if residual is None else Ho * Wo * residual.shape[3])
+    bmax = max(1, (_H2_SPAN_MAX - 1) // per_img)
+    for b0 in range(0, B, bmax):
+        b1 = min(B, b0 + bmax)
+        xs, os_, rs = x[b0:b1], out[b0:b1], None if residual is None else residual[b0:b1]
+        d = _abi.ConvDesc(B=b1 - b0, H=H, W=W, Cin=cw.cin, Cout=cw.cout, kh=cw.kh, kw=cw.kw, sh=sh, sw=sw, pt=pt, pl=pl, Ho=Ho, Wo=Wo,
+                          groups=cw.groups, ldx=ldx, cin_off=cin_off, ldy=out.shape[3], cout_off=cout_off,
+                          ldr=0 if residual is None else residual.shape[3], res_off=0, ldw=cw.ldw, act_pre=_act(act), act_post=_act(act_post))
+        tok = None
+        if _PROF is not None:
+            M = (b1 - b0) * Ho * Wo
+            kk = cw.kh * cw.kw * cw.alg_cin_g
+            tok = _PROF.start("h2:" + (conv_kernel_name_h2(d, residual is not None) or "unsupported"), 2.0 * M * cw.cout * kk,
+                              4.0 * ((b1 - b0) * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1)) + 2.0 * cw.w.numel(),
+                              f"M={M} N={cw.cout} K={cw.kh * cw.kw * cw.cin_g} k{cw.kh} s{sh} g{cw.groups}")
+        st = _abi.lib().vip_conv2d_nhwc_h2(_p(xs), _p(cw.w), _p(cw.bias), _p(rs), _p(os_), C.byref(d), 1.0 / cw.h2_scale,
+                                           _p(h2_status()), _stream())
+        if tok is not None:
+            _PROF.stop(tok)
+        _abi.check(st, "vip_conv2d_nhwc_h2")
+    return out
+
+
 def _conv2d_s32(x, cw: ConvWeight, stride, pad, act, act_post, residual, out, cin_off, cout_off, gate):
-    """STRICT conv2d: fp32 x / weights / residual / out, vip_conv2d_nhwc_s32; a gate [B, Cin] fp32 is multiplied in first."""
+    """fp32-storage conv2d: fp32 x / weights / residual / out, vip_conv2d_nhwc_s32; a gate [B, Cin] fp32 is multiplied in first."""
     if not cw.strict:
-        raise _abi.VipError("conv2d: fp32 activations with fp16 weights - build the model under ops.precision('strict')")
+        raise _abi.VipError("conv2d: fp32 activations with fp16 weights - build the model under ops.precision('f32')")
     if gate is not None:
         assert gate.shape == (x.shape[0], cw.cin) and x.shape[3] == cw.cin and cin_off == 0, (gate.shape, x.shape, cw.cin)
         x = scale_add_act(x, gate, None, None)
@@ -460,10 +636,14 @@ def _conv2d_s32(x, cw: ConvWeight, stride, pad, act, act_post, residual, out, ci
 
 def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Optional[torch.Tensor] = None):
     """Dense over the last axis of ``x`` (any leading shape)."""
-    if _is32(x, "dense.x"):
+    kind = _kind(x, "dense.x")
+    if kind != "f16":
+        if kind != cw.kind:
+            raise _abi.VipError(f"dense: {kind} activations with {cw.kind} weights - build the model and its input in the same precision")
         lead, K = x.shape[:-1], x.shape[-1]
         r4 = None if residual is None else residual.reshape(-1, 1, 1, cw.cout)
-        return _conv2d_s32(x.reshape(-1, 1, 1, K), cw, 1, (0, 0, 0, 0), act, act_post, r4, None, 0, 0, None).reshape(*lead, cw.cout)
+        fn = _conv2d_s32 if kind == "s32" else _conv2d_h2
+        return fn(x.reshape(-1, 1, 1, K), cw, 1, (0, 0, 0, 0), act, act_post, r4, None, 0, 0, None).reshape(*lead, cw.cout)
     if _CALIB and cw.err is not None:
         _bias_correct(cw, x)
     if _EXACT and cw.exact is not None:
@@ -498,7 +678,7 @@ def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual:
     """``fc2(act(fc1(LN(x)))) (+ residual)`` over the last axis; ``ln = (gamma, beta, eps)`` or None.  One fused launch
     (LayerNorm in the prologue, hidden tensor in registers) when the C ABI supports the shape, otherwise LayerNorm +
     two Dense launches - same arithmetic either way."""
-    if _is32(x, "mlp.x"):        # STRICT: LayerNorm, Dense + activation, Dense (+ residual) as three fp32 launches
+    if _kind(x, "mlp.x") != "f16":        # STRICT: LayerNorm, Dense + activation, Dense (+ residual) as three launches
         if ln is not None:
             x = layernorm(x, ln[0], ln[1], float(ln[2]))
         return dense(dense(x, fc1, act=act), fc2, residual=residual)
@@ -536,7 +716,7 @@ def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmo
     One launch (vip_se_gate_f16: a workgroup per image, matrix-vector products out of L2) when the two weight matrices
     are small - every image re-reads them, so for wide gates (ResNet-RS / ResNeSt: Cr = C/4) the pool + two batched
     GEMMs are cheaper and are used instead (the last one with the split epilogue)."""
-    if _is32(x, "se_gate.x"):    # STRICT: pool -> Dense -> Dense, the gate is a plain fp32 [B, C]
+    if _kind(x, "se_gate.x") != "f16":    # STRICT: pool -> Dense -> Dense, the gate is a plain [B, C] in the activation storage
         return dense(dense(global_avgpool(x), fc1, act=act1), fc2, act=act2)
     B, H, W, Cc = x.shape
     assert fc1.groups == 1 and fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1
@@ -555,7 +735,7 @@ def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmo
 def dense_split(x: torch.Tensor, cw: ConvWeight, act=None) -> torch.Tensor:
     """Dense on a few rows with the output as two fp16 planes ``[M, 2, N]`` (``fp16(v)``, ``fp16(v - fp16(v))``).  ``x`` is ``[M, K]``
     or itself split, ``[M, 2, K]`` (a pooled vector from ``global_avgpool(split=True)`` or the previous layer of the chain)."""
-    if _is32(x, "dense_split.x"):    # STRICT: fp32 vectors need no hi / lo planes
+    if _kind(x, "dense_split.x") != "f16":    # STRICT: the vectors need no extra hi / lo planes
         return dense(x, cw, act=act)
     split_in = x.dim() == 3
     assert x.dim() == 2 or (split_in and x.shape[1] == 2), x.shape
@@ -579,7 +759,7 @@ def dense_split(x: torch.Tensor, cw: ConvWeight, act=None) -> torch.Tensor:
 
 def dwconv2d(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride=1, pad=(0, 0, 0, 0), act=None):
     """Depthwise conv; ``w_khwc`` fp32 ``[k,k,C]``, bias fp32 ``[C]``."""
-    s32 = _is32(x, "dwconv2d.x")
+    kind = _kind(x, "dwconv2d.x")
     if w_khwc.dtype != torch.float32 or not w_khwc.is_contiguous() or w_khwc.shape != (k, k, x.shape[-1]):
         raise ValueError("dwconv2d: the filter must be a contiguous fp32 [k,k,C] tensor")
     B, H, W, Cc = x.shape
@@ -587,10 +767,8 @@ def dwconv2d(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stri
     Ho = (H + pt + pb - k) // stride + 1
     Wo = (W + pl + pr - k) // stride + 1
     out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
-    if s32:
-        st = _abi.lib().vip_dwconv2d_nhwc_s32(_p(x), _p(w_khwc), _p(bias), _p(out), B, H, W, Cc, k, stride, pt, pl, Ho, Wo,
-                                              _act(act), _stream())
-        _abi.check(st, "vip_dwconv2d_nhwc_s32")
+    if kind != "f16":
+        _strict_call("dwconv2d_nhwc", kind, _p(x), _p(w_khwc), _p(bias), _p(out), B, H, W, Cc, k, stride, pt, pl, Ho, Wo, _act(act))
         return out
     st = _abi.lib().vip_dwconv2d_nhwc_f16(_p(x), _p(w_khwc), _p(bias), _p(out), B, H, W, Cc, k, stride, pt, pl,
                                           Ho, Wo, _act(act), _stream())
@@ -664,13 +842,12 @@ def mbconv_expand_dw(x, cw: ConvWeight, w_khwc: torch.Tensor, dw_bias: Optional[
 
 
 def layernorm(x, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
-    s32 = _is32(x, "layernorm.x")
+    kind = _kind(x, "layernorm.x")
     Cc = x.shape[-1]
     rows = x.numel() // Cc
     out = torch.empty_like(x)
-    if s32:
-        st = _abi.lib().vip_layernorm_s32(_p(x), _p(gamma), _p(beta), _p(out), rows, Cc, float(eps), _stream())
-        _abi.check(st, "vip_layernorm_s32")
+    if kind != "f16":
+        _strict_call("layernorm", kind, _p(x), _p(gamma), _p(beta), _p(out), rows, Cc, float(eps))
         return out
     st = _abi.lib().vip_layernorm_f16(_p(x), _p(gamma), _p(beta), _p(out), rows, Cc, float(eps), _stream())
     _abi.check(st, "vip_layernorm_f16")
@@ -683,7 +860,7 @@ POOL_MAX_ZEROPAD, POOL_AVG_VALID, POOL_AVG_FULL = 0, 1, 2
 def pool2d(x, k: int, stride: int, pad=(0, 0, 0, 0), mode=POOL_MAX_ZEROPAD, out_hw=None):
     """``out_hw`` = (Ho, Wo) asks for fewer output rows / columns than the padding implies (a top-left crop); with k = 1,
     stride 1 and zero-pad max pooling the op is a zero-padded copy (GCViT FitWindow) or a crop (level.py:61)."""
-    s32 = _is32(x, "pool2d.x")
+    kind = _kind(x, "pool2d.x")
     B, H, W, Cc = x.shape
     pt, pb, pl, pr = pad
     Ho = (H + pt + pb - k) // stride + 1
@@ -692,9 +869,8 @@ def pool2d(x, k: int, stride: int, pad=(0, 0, 0, 0), mode=POOL_MAX_ZEROPAD, out_
         assert out_hw[0] <= Ho and out_hw[1] <= Wo
         Ho, Wo = out_hw
     out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
-    if s32:
-        st = _abi.lib().vip_pool2d_nhwc_s32(_p(x), _p(out), B, H, W, Cc, Cc, Cc, k, stride, pt, pl, Ho, Wo, mode, _stream())
-        _abi.check(st, "vip_pool2d_nhwc_s32")
+    if kind != "f16":
+        _strict_call("pool2d_nhwc", kind, _p(x), _p(out), B, H, W, Cc, Cc, Cc, k, stride, pt, pl, Ho, Wo, mode)
         return out
     st = _abi.lib().vip_pool2d_nhwc_f16(_p(x), _p(out), B, H, W, Cc, Cc, Cc, k, stride, pt, pl, Ho, Wo, mode,
                                         _stream())
@@ -706,10 +882,10 @@ def global_avgpool(x, split: bool = False):
     """[B,H,W,C] (or [B,N,C]) -> [B,C]; ``split``: [B,2,C], the mean as a hi and a lo fp16 plane (for ``dense_split``)."""
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
-    if _is32(x, "global_avgpool.x"):     # STRICT: fp32 [B, C] whatever ``split`` says
-        out = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
-        st = _abi.lib().vip_global_avgpool_s32(_p(x), _p(out), B, HW, Cc, Cc, _stream())
-        _abi.check(st, "vip_global_avgpool_s32")
+    kind = _kind(x, "global_avgpool.x")
+    if kind != "f16":     # STRICT: [B, C] in the activation storage whatever ``split`` says
+        out = torch.empty((B, Cc), dtype=x.dtype, device=x.device)
+        _strict_call("global_avgpool", kind, _p(x), _p(out), B, HW, Cc, Cc)
         return out
     out = torch.empty((B, 2, Cc) if split else (B, Cc), dtype=torch.float16, device=x.device)
     fn = "vip_global_avgpool_split_f16" if split else "vip_global_avgpool_f16"
@@ -721,15 +897,14 @@ def global_avgpool(x, split: bool = False):
 def gap_dense_f32(x, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     """Classifier head: mean over the middle axes of ``x`` ([B,...,C]) then Dense -> fp32 ``[B,N]``.
     ``w_nc`` fp32 ``[N,C]``."""
-    s32 = _is32(x, "gap_dense_f32.x")
+    kind = _kind(x, "gap_dense_f32.x")
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
     N = w_nc.shape[0]
     assert w_nc.dtype == torch.float32 and w_nc.shape == (N, Cc) and w_nc.is_contiguous()
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
-    if s32:
-        st = _abi.lib().vip_gap_ln_dense_s32(_p(x), None, None, 0.0, _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, HW * Cc, N, _stream())
-        _abi.check(st, "vip_gap_ln_dense_s32")
+    if kind != "f16":
+        _strict_call("gap_ln_dense", kind, _p(x), None, None, 0.0, _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, HW * Cc, N, status=False)
         return out
     st = _abi.lib().vip_gap_dense_f32(_p(x), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, N, _stream())
     _abi.check(st, "vip_gap_dense_f32")
@@ -739,17 +914,16 @@ def gap_dense_f32(x, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
 def gap_ln_dense_f32(x, gamma: torch.Tensor, beta: torch.Tensor, eps: float, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     """Classifier head with a LayerNorm on the pooled vector: mean over the middle axes of ``x`` ([B,...,C]) -> LayerNorm over C
     -> Dense, fp32 throughout -> fp32 ``[B,N]``.  ``gamma``/``beta`` fp32 ``[C]``, ``w_nc`` fp32 ``[N,C]``."""
-    s32 = _is32(x, "gap_ln_dense_f32.x")
+    kind = _kind(x, "gap_ln_dense_f32.x")
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
     N = w_nc.shape[0]
     assert w_nc.dtype == torch.float32 and w_nc.shape == (N, Cc) and w_nc.is_contiguous()
     assert gamma.dtype == beta.dtype == torch.float32 and gamma.shape == beta.shape == (Cc,)
     out = torch.empty((B, N), dtype=torch.float32, device=x.device)
-    if s32:
-        st = _abi.lib().vip_gap_ln_dense_s32(_p(x), _p(gamma), _p(beta), float(eps), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc,
-                                             HW * Cc, N, _stream())
-        _abi.check(st, "vip_gap_ln_dense_s32")
+    if kind != "f16":
+        _strict_call("gap_ln_dense", kind, _p(x), _p(gamma), _p(beta), float(eps), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, HW * Cc, N,
+                     status=False)
         return out
     st = _abi.lib().vip_gap_ln_dense_f32(_p(x), _p(gamma), _p(beta), float(eps), _p(w_nc), _p(bias), _p(out), B, HW, Cc, Cc, N,
                                          _stream())
@@ -805,17 +979,17 @@ def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
     ``scale`` is [B, C] fp16 or a split gate [B, 2, C] (planes summed in fp32)."""
     B, Cc = x.shape[0], x.shape[-1]
     HW = x.numel() // (B * Cc)
-    if _is32(x, "scale_add_act.x"):      # STRICT: scale is a plain fp32 [B, C]
+    kind = _kind(x, "scale_add_act.x")
+    if kind != "f16":      # STRICT: scale is a plain [B, C] in the activation storage
         if scale is not None:
-            _chk32(scale, "scale_add_act.scale")
+            _chk_kind(scale, kind, "scale_add_act.scale")
             assert scale.shape == (B, Cc), scale.shape
         if residual is not None:
-            _chk32(residual, "scale_add_act.residual")
+            _chk_kind(residual, kind, "scale_add_act.residual")
             assert residual.shape == x.shape
         out = torch.empty_like(x)
         out2 = torch.empty_like(x) if act2 is not None else None
-        st = _abi.lib().vip_scale_add_act_s32(_p(x), _p(scale), _p(residual), _p(out), _p(out2), B, HW, Cc, _act(act), _act(act2), _stream())
-        _abi.check(st, "vip_scale_add_act_s32")
+        _strict_call("scale_add_act", kind, _p(x), _p(scale), _p(residual), _p(out), _p(out2), B, HW, Cc, _act(act), _act(act2))
         return out if act2 is None else (out, out2)
     planes = 1
     if scale is not None:
@@ -835,19 +1009,17 @@ def scale_add_act(x, scale=None, residual=None, act=None, act2=None):
 
 def window_attention(qkv, q_global, bias_table, heads: int, ws: int, scale: float):
     """GCViT window attention core on feature-map layout.  qkv ``[B,Hp,Wp,nq*C]``; q_global ``[B,ws*ws,C]`` or None."""
-    s32 = _is32(qkv, "window_attention.qkv")
+    kind = _kind(qkv, "window_attention.qkv")
     B, Hp, Wp, CC = qkv.shape
     nq = 2 if q_global is not None else 3
     Cc = CC // nq
     if q_global is not None:
-        (_chk32 if s32 else _chk16)(q_global, "window_attention.q_global")
+        _chk_kind(q_global, kind, "window_attention.q_global")
         assert q_global.numel() == B * ws * ws * Cc
     assert bias_table.dtype == torch.float32 and bias_table.shape == ((2 * ws - 1) ** 2, heads)
     out = torch.empty((B, Hp, Wp, Cc), dtype=qkv.dtype, device=qkv.device)
-    if s32:
-        st = _abi.lib().vip_window_attn_fwd_s32(_p(qkv), _p(q_global), _p(bias_table), _p(out), B, Hp, Wp, Cc, heads, ws, nq,
-                                                float(scale), _stream())
-        _abi.check(st, "vip_window_attn_fwd_s32")
+    if kind != "f16":
+        _strict_call("window_attn_fwd", kind, _p(qkv), _p(q_global), _p(bias_table), _p(out), B, Hp, Wp, Cc, heads, ws, nq, float(scale))
         return out
     tok = None
     if _PROF is not None:
@@ -910,13 +1082,12 @@ def gcvit_attn_block(x, q_global, ln, qkv: ConvWeight, proj: ConvWeight, bias_ta
 
 def mhsa(qkv, heads: int, scale: float):
     """ViT attention core: qkv ``[B,N,3D]`` -> ``[B,N,D]``."""
-    s32 = _is32(qkv, "mhsa.qkv")
+    kind = _kind(qkv, "mhsa.qkv")
     B, N, D3 = qkv.shape
     D = D3 // 3
     out = torch.empty((B, N, D), dtype=qkv.dtype, device=qkv.device)
-    if s32:
-        st = _abi.lib().vip_mhsa_fwd_s32(_p(qkv), _p(out), B, N, D, heads, float(scale), _stream())
-        _abi.check(st, "vip_mhsa_fwd_s32")
+    if kind != "f16":
+        _strict_call("mhsa_fwd", kind, _p(qkv), _p(out), B, N, D, heads, float(scale))
         return out
     st = _abi.lib().vip_mhsa_fwd_f16(_p(qkv), _p(out), B, N, D, heads, float(scale), _stream())
     _abi.check(st, "vip_mhsa_fwd_f16")
@@ -928,6 +1099,8 @@ def to_device_nhwc8(x_nhwc3: torch.Tensor, device="cuda", dtype: Optional[torch.
     to 8 (the layout vip_resize_bicubic_norm_f16 / _s32 emit), fp16 or - ``dtype=torch.float32``, the STRICT path - fp32."""
     B, H, W, Cc = x_nhwc3.shape
     dtype = dtype or torch.float16
+    if dtype == PACKED:                     # the packed STRICT storage: pad in fp32, then split on the device
+        return pack_h2(to_device_nhwc8(x_nhwc3, device, torch.float32))
     out = torch.zeros((B, H, W, 8), dtype=dtype, device=device)
     out[..., :Cc] = x_nhwc3.to(device=device, dtype=dtype)
     return out
@@ -935,14 +1108,13 @@ def to_device_nhwc8(x_nhwc3: torch.Tensor, device="cuda", dtype: Optional[torch.
 
 def vit_tokens(patches, cls_token, pos_embed):
     """[B,NP,D] patches + cls [D] + pos [NP+1,D] -> [B,NP+1,D] (tfimm vit.py:419-426)."""
-    s32 = _is32(patches, "vit_tokens.patches")
+    kind = _kind(patches, "vit_tokens.patches")
     B, NP, D = patches.shape
     assert cls_token.numel() == D and pos_embed.numel() == (NP + 1) * D
     assert cls_token.dtype == pos_embed.dtype == patches.dtype, "vit_tokens: cls / pos must be stored in the activation dtype"
     out = torch.empty((B, NP + 1, D), dtype=patches.dtype, device=patches.device)
-    if s32:
-        st = _abi.lib().vip_vit_tokens_s32(_p(patches), _p(cls_token), _p(pos_embed), _p(out), B, NP, D, _stream())
-        _abi.check(st, "vip_vit_tokens_s32")
+    if kind != "f16":
+        _strict_call("vit_tokens", kind, _p(patches), _p(cls_token), _p(pos_embed), _p(out), B, NP, D)
         return out
     st = _abi.lib().vip_vit_tokens_f16(_p(patches), _p(cls_token), _p(pos_embed), _p(out), B, NP, D, _stream())
     _abi.check(st, "vip_vit_tokens_f16")
@@ -951,14 +1123,13 @@ def vit_tokens(patches, cls_token, pos_embed):
 
 def cls_dense_f32(tokens, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
     """Dense head on token 0 of ``[B,N,D]`` (ViT ``head(norm(x)[:, 0])``) -> fp32 ``[B,classes]``."""
-    s32 = _is32(tokens, "cls_dense_f32.tokens")
+    kind = _kind(tokens, "cls_dense_f32.tokens")
     B, N, D = tokens.shape
     n_out = w_nc.shape[0]
     assert w_nc.dtype == torch.float32 and w_nc.shape == (n_out, D) and w_nc.is_contiguous()
     out = torch.empty((B, n_out), dtype=torch.float32, device=tokens.device)
-    if s32:
-        st = _abi.lib().vip_gap_ln_dense_s32(_p(tokens), None, None, 0.0, _p(w_nc), _p(bias), _p(out), B, 1, D, D, N * D, n_out, _stream())
-        _abi.check(st, "vip_gap_ln_dense_s32")
+    if kind != "f16":
+        _strict_call("gap_ln_dense", kind, _p(tokens), None, None, 0.0, _p(w_nc), _p(bias), _p(out), B, 1, D, D, N * D, n_out, status=False)
         return out
     st = _abi.lib().vip_gap_dense_f32(_p(tokens), _p(w_nc), _p(bias), _p(out), B, 1, D, N * D, n_out, _stream())
     _abi.check(st, "vip_gap_dense_f32")
@@ -968,14 +1139,13 @@ def cls_dense_f32(tokens, w_nc: torch.Tensor, bias: Optional[torch.Tensor]):
 def mul(a: torch.Tensor, b: torch.Tensor, c: int, a_off: int = 0, b_off: int = 0) -> torch.Tensor:
     """``a[..., a_off:a_off+c] * b[..., b_off:b_off+c]`` -> contiguous ``[..., c]`` (the operands are read in place as
     channel slices of their full tensors)."""
-    s32 = _is32(a, "mul.a")
-    (_chk32 if s32 else _chk16)(b, "mul.b")
+    kind = _kind(a, "mul.a")
+    _chk_kind(b, kind, "mul.b")
     assert a.shape[:-1] == b.shape[:-1]
     rows = a.numel() // a.shape[-1]
     out = torch.empty((*a.shape[:-1], c), dtype=a.dtype, device=a.device)
-    if s32:
-        st = _abi.lib().vip_mul_s32(_p(a), _p(b), _p(out), rows, c, a.shape[-1], a_off, b.shape[-1], b_off, c, 0, _stream())
-        _abi.check(st, "vip_mul_s32")
+    if kind != "f16":
+        _strict_call("mul", kind, _p(a), _p(b), _p(out), rows, c, a.shape[-1], a_off, b.shape[-1], b_off, c, 0)
         return out
     st = _abi.lib().vip_mul_f16(_p(a), _p(b), _p(out), rows, c, a.shape[-1], a_off, b.shape[-1], b_off, c, 0, _stream())
     _abi.check(st, "vip_mul_f16")
@@ -987,12 +1157,12 @@ def radix_combine(x, scale, radix: int = 2):
     -> ``[B,H,W,C]``."""
     B, H, W, RC = x.shape
     Cc = RC // radix
-    if _is32(x, "radix_combine.x"):
-        _chk32(scale, "radix_combine.scale")
+    kind = _kind(x, "radix_combine.x")
+    if kind != "f16":
+        _chk_kind(scale, kind, "radix_combine.scale")
         assert scale.shape == (B, RC), scale.shape
-        out = torch.empty((B, H, W, Cc), dtype=torch.float32, device=x.device)
-        st = _abi.lib().vip_radix_combine_s32(_p(x), _p(scale), _p(out), B, H * W, Cc, radix, _stream())
-        _abi.check(st, "vip_radix_combine_s32")
+        out = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
+        _strict_call("radix_combine", kind, _p(x), _p(scale), _p(out), B, H * W, Cc, radix)
         return out
     _chk16(scale, "radix_combine.scale")
     assert scale.shape in ((B, RC), (B, 2, RC)), scale.shape

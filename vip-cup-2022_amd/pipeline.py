@@ -74,6 +74,9 @@ class DecodedBatch:
         """cast -> tf.image.resize(bicubic) -> /255 (dataset/dataset.py:31-38) -> NHWC, channels padded; fp16, or with
         ``dtype=torch.float32`` (the STRICT path) the unrounded fp32 values the reference's pipeline produces."""
         n, maxH, maxW, _ = self.rgb.shape
+        from . import ops
+        if dtype == ops.PACKED:                      # packed STRICT storage: the fp32 pipeline values, split once on the device
+            return ops.pack_h2(self.resized(out_h, out_w, c_out, torch.float32))
         out = torch.empty((n, out_h, out_w, c_out), dtype=dtype, device=self.rgb.device)
         fn = {torch.float16: "vip_resize_bicubic_norm_f16", torch.float32: "vip_resize_bicubic_norm_s32"}[dtype]
         st = getattr(_abi.lib(), fn)(_p(self.rgb), _p(self.sizes), _p(bicubic_table(self.rgb.device)), n,
@@ -118,6 +121,9 @@ def apply_augment(x: torch.Tensor, hflip, vflip, gray) -> torch.Tensor:
     flags = (torch.as_tensor(hflip, dtype=torch.int32) | (torch.as_tensor(vflip, dtype=torch.int32) << 1) |
              (torch.as_tensor(gray, dtype=torch.int32) << 2)).to(x.device)
     assert flags.numel() == B
+    from . import ops
+    if x.dtype == ops.PACKED:                        # flips / grey on the joined fp32 values, split again
+        return ops.pack_h2(apply_augment(ops.unpack_h2(x), hflip, vflip, gray))
     out = torch.empty_like(x)
     fn = "vip_tta_augment_s32" if x.dtype == torch.float32 else "vip_tta_augment_f16"
     st = getattr(_abi.lib(), fn)(_p(x), _p(out), _p(flags), B, H, W, Cc, _stream())
@@ -304,7 +310,8 @@ def keras_predict(cls):
 
     def checked(self, t):
         prec = getattr(self, "precision", None)           # set by zoo.construct; absent on hand-built models (no check)
-        if prec is not None and t.dtype != (torch.float32 if prec == "strict" else torch.float16):
+        from . import ops
+        if prec is not None and t.dtype != ops.act_dtype(prec):
             raise _abi.VipError(f"{type(self).__name__}.predict: a {prec} model got a {t.dtype} batch "
                                 "(DecodedBatch.resized(..., dtype=...) / build_dataset with CFG.precision pick the input dtype)")
         return batch_predict(self, t)

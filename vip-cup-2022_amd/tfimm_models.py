@@ -149,8 +149,8 @@ class ViT:
         D = cfg.embed_dim
         assert D // cfg.nb_heads == 64, "vip_mhsa_fwd_f16 implements head_dim 64"
         self.patch = ops.make_conv_weight(p["patch_embed/proj/kernel"], p["patch_embed/proj/bias"], device=dev, pad_cin_to=8)
-        self.cls = p["cls_token"].reshape(D).to(dev, ops.act_dtype()).contiguous()      # stored like an activation (fp32 when strict)
-        self.pos = p["pos_embed"].reshape(-1, D).to(dev, ops.act_dtype()).contiguous()
+        self.cls = ops.to_act(p["cls_token"].reshape(D), dev)      # stored like an activation (packed pairs when strict, fp32 in f32 mode)
+        self.pos = ops.to_act(p["pos_embed"].reshape(-1, D), dev)
         self._pos32 = p["pos_embed"].reshape(-1, D).to(torch.float32)                  # host copy: source of interpolated grids
         self._pos_by_grid = {tuple(cfg.grid_size): self.pos}
         self._act_dtype, self._dev = ops.act_dtype(), dev
@@ -180,7 +180,7 @@ class ViT:
         grid = (pe.shape[1], pe.shape[2])
         if grid not in self._pos_by_grid:                                # vit.py:425-433: embeddings resampled to the input's patch grid
             pos = interpolate_pos_embeddings(self._pos32, cfg.grid_size, grid, nb_tokens=1)
-            self._pos_by_grid[grid] = pos.to(self._dev, self._act_dtype).contiguous()
+            self._pos_by_grid[grid] = ops.to_act(pos, self._dev, self._act_dtype)
         t = ops.vit_tokens(pe.reshape(B, grid[0] * grid[1], cfg.embed_dim), self.cls, self._pos_by_grid[grid])
         scale = (cfg.embed_dim // cfg.nb_heads) ** -0.5
         for blk in self.blocks:                                          # ViTBlock.call (vit.py:214-227)

@@ -80,7 +80,7 @@ class Workload:
                  costs: Optional[Sequence[float]] = None, distinct_batches: int = 1):
         """``jpegs``: one batch of JPEG byte strings, or a list of batches (lists) the steps cycle through; default: ``distinct_batches``
         batches of the synthetic generator (images 0 .. distinct_batches * batch - 1: with 20 batches of 256 the timed steps walk the
-        5 120 distinct files of BASELINE config 5's "5 000-image set").  ``precision``: "fast" | "strict" (None = ops.PRECISION).
+        5 120 distinct files of BASELINE config 5's "5 000-image set").  ``precision``: "fast" | "strict" | "f32" (None = ops.PRECISION).
         ``costs``: measured ms / image per member for the hybrid plan (identical on every rank)."""
         self.name, self.batch, self.rank, self.world, self.members = name, batch, rank, world, members
         self.shard, self.resident = shard, resident
@@ -212,7 +212,7 @@ class Workload:
                 "precision": self.precision, "distinct_images": len(self.jpeg_batches) * self.batch,
                 "batch_per_shard": self.batch, "global_batch": self.batch * self.world,
                 "input": inp + " -> bicubic resize + /255 per member resolution -> "
-                         + ("fp32" if self.precision == "strict" else "fp16") + " NHWC",
+                         + {"fast": "fp16", "strict": "packed fp16-pair (22-bit)", "f32": "fp32"}[self.precision] + " NHWC",
                 "parallelism": par + ", one all-gather of scores", "shard": self.shard,
                 "member_streams": self.member_streams.n}
 

@@ -134,7 +134,10 @@ def construct(spec: MemberSpec, params, bias_calibration: bool = True, precision
       weight-rounding error is folded into the fp32 biases) over ``calibration_batch`` (a ``pipeline.DecodedBatch``; default: the
       seeded synthetic batch ``pipeline.calibration_batch()`` - pass a few REAL images when the checkpoints are real, the correction
       needs typical per-channel input means).  ``bias_calibration=False`` (or env ``VIP_BIAS_CALIBRATION=0``) gives the plain fp16 model.
-    * ``"strict"``: fp32 weights exactly as in the checkpoint, nothing to calibrate; the model takes fp32 inputs.
+    * ``"strict"``: every weight as an fp16 (hi, lo) pair (22 bits), nothing to calibrate; the model takes packed-strict inputs
+      (``ops.PACKED``) and every member's logit is within the 1e-3 of BASELINE.json (measured <= 1e-4).
+    * ``"f32"``: fp32 weights exactly as in the checkpoint, fp32 activations (round 3's strict mode; the fallback when an activation
+      leaves the fp16 range of the packed storage).
 
     ``variant``: constructor arguments that differ from the member's defaults (``variant_kwargs``: what a checkpoint's model_config says
     about first_strides / classes / head activation).
@@ -142,10 +145,10 @@ def construct(spec: MemberSpec, params, bias_calibration: bool = True, precision
     from . import ops, pipeline
     mode = precision or ops.PRECISION
     ctor = (lambda p: spec.ctor(p, **variant)) if variant else spec.ctor
-    if mode == "strict":
-        with ops.precision("strict"):
+    if mode in ("strict", "f32"):
+        with ops.precision(mode):
             model = ctor(params)
-        model.precision = "strict"
+        model.precision = mode
         return model
     with ops.precision("fast"):
         if os.environ.get("VIP_BIAS_CALIBRATION", "1") == "0":     # profiling runs: keep the calibration launches out of the trace
