@@ -406,6 +406,10 @@ int vip_conv2d_kernel_name_h2(const vip_conv_desc* d, int has_residual, char* na
  * gamma / beta, depthwise filters, head matrices, relative-position table) and fp32 head outputs as there */
 int vip_dwconv2d_nhwc_h2(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k, int stride,
                          int pt, int pl, int Ho, int Wo, int act, int* status, void* stream);
+/* vip_se_gate_f16 on the packed storage: gate [B][Cout] packed; w1 / w2 packed rows of W * scale (ldw in halfs), b = bias * scale,
+ * s1 / s2 = 1 / scale */
+int vip_se_gate_h2(const void* x, const void* w1, const float* b1, float s1, const void* w2, const float* b2, float s2, void* gate,
+                   int B, int HW, int C, int ldx, int Cr, int ldw1, int Cout, int ldw2, int act1, int act2, int* status, void* stream);
 int vip_layernorm_h2(const void* x, const float* gamma, const float* beta, void* y, int rows, int C, float eps, int* status, void* stream);
 int vip_pool2d_nhwc_h2(const void* x, void* y, int B, int H, int W, int C, int ldx, int ldy, int k, int stride, int pt, int pl, int Ho,
                        int Wo, int mode, int* status, void* stream);

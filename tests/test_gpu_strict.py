@@ -201,7 +201,9 @@ def test_norm_pool_heads_strict(mode, report):
     check(report, "mul", ops.mul(act(a), act(b), 16, 32, 8), a[..., 32:48] * b[..., 8:24])
 
 
-@pytest.mark.parametrize("ws,heads,nwin,glob", [(7, 2, (2, 3), False), (7, 4, (1, 2), True), (14, 8, (1, 1), False), (14, 8, (1, 1), True)])
+# ws 7 / 14: the matrix-core kernel (attn_h2.hip) in the packed mode; ws 5: the fp32 VALU kernel in both storages
+@pytest.mark.parametrize("ws,heads,nwin,glob", [(7, 2, (2, 3), False), (7, 4, (1, 2), True), (14, 8, (1, 1), False), (14, 8, (1, 1), True),
+                                                (14, 8, (2, 1), False), (5, 2, (2, 2), False), (5, 2, (1, 2), True)])
 @pytest.mark.parametrize("mode", MODES)
 def test_window_attention_strict(ws, heads, nwin, glob, mode, report):
     ops = _ops()
@@ -226,10 +228,11 @@ def test_window_attention_strict(ws, heads, nwin, glob, mode, report):
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_mhsa_strict(mode, report):
+@pytest.mark.parametrize("N", [197, 50, 224])
+def test_mhsa_strict(N, mode, report):
     ops = _ops()
     g = torch.Generator().manual_seed(11)
-    B, N, heads = 3, 197, 3
+    B, heads = 3, 3
     D = heads * 64
     qkv = torch.randn(B, N, 3 * D, generator=g)
     got = ops.mhsa(A(qkv, mode), heads, 64 ** -0.5)

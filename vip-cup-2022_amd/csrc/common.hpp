@@ -46,6 +46,13 @@ static inline int vip_launch_status(const char* what) {
 int vip_dwconv_tiled(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                      int pt, int pl, int Ho, int Wo, int act, hipStream_t s, float* partials = nullptr, int parts = 0);
 int vip_dwconv_tiled_parts(int B, int H, int W, int C, int k, int Ho, int Wo);
+// the same on the packed STRICT storage (dwconv.hip); returns 1 when the shape is not handled there
+int vip_dwconv_tiled_h2(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k, int pt, int pl, int Ho,
+                        int Wo, int act, int* status, hipStream_t s);
+// attention cores of the packed STRICT storage on the matrix cores (attn_h2.hip); return 1 when the configuration is not built there
+int vip_window_attn_h2_mfma(const void* qkv, const void* q_global, const float* bias_table, void* out, int B, int Hp, int Wp, int C, int heads,
+                            int ws, int nq, float scale, int* status, hipStream_t s);
+int vip_mhsa_h2_mfma(const void* qkv, void* out, int B, int N, int D, int heads, float scale, int* status, hipStream_t s);
 // stride-1 7x7 / 5x5 depthwise on the matrix cores (dwconv_mfma.hip); returns 1 when the shape is not handled there
 int vip_dwconv_mfma(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k,
                     int pt, int pl, int Ho, int Wo, int act, hipStream_t s);

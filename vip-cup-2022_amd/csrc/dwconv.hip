@@ -225,6 +225,174 @@ __global__ __launch_bounds__(256, 2) void dwconv_tile_kernel(const f16* __restri
     }   // tile loop
 }
 
+// ---- the same register-tiled scheme on the packed STRICT storage (common.hpp: 8 channels = [hi x 8][lo x 8], 4 bytes per element) ----
+// A thread owns a T x TW patch of output pixels for FOUR channels (half a 32-byte group: 8 + 8 bytes per pixel) - with eight, the raw
+// row, its prefetched successor, the joined fp32 row and the accumulators do not fit 256 registers.  Values are joined to fp32 once
+// per input element (hi + lo), the filter is fp32 in LDS as above, accumulation and activation are fp32 (vip_act_strict), the result
+// is split again on the store and checked against the fp16 range.  Replaces the same DepthwiseConv2D call sites (strict mode).
+template <int K, int T, int TW, bool WHOLE>
+__global__ __launch_bounds__(256, 2) void dwconv_tile_h2_kernel(const char* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, char* __restrict__ y, int B, int H, int W,
+                                                                int C, int pt, int pl, int Ho, int Wo, int act, int cb_chunks, int tiles_x,
+                                                                int tiles_y, long n_tiles, long x_bytes, int* status) {
+    constexpr int P = T + K - 1;
+    constexpr int PW = TW + K - 1;
+    extern __shared__ __attribute__((aligned(16))) float wlds[];  // [K*K][cb_chunks*4] fp32
+
+    const int c4_0 = blockIdx.y * cb_chunks;               // first 4-channel chunk of this block
+    const int C4 = C >> 2;
+    const int nch = min(cb_chunks, C4 - c4_0);
+    for (int i = threadIdx.x; i < K * K * nch * 4; i += 256) {
+        const int tap = i / (nch * 4), c = i - tap * (nch * 4);
+        wlds[tap * (cb_chunks * 4) + c] = w[(long)tap * C + c4_0 * 4 + c];
+    }
+    __syncthreads();
+
+    const int tiles_per_block = 256 / cb_chunks;
+    const int lc = threadIdx.x % cb_chunks;
+    const int lt = threadIdx.x / cb_chunks;
+    if (!(lt < tiles_per_block && lc < nch)) return;
+    const int c0 = (c4_0 + lc) * 4;
+    const unsigned coff = (unsigned)((c0 >> 3) * 32 + ((c0 >> 2) & 1) * 8);      // byte offset of the hi quad inside a pixel; lo: + 16
+    const float* wl = wlds + lc * 4;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, (unsigned)x_bytes, 0x00020000);
+
+    const long n_groups = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    long g_lo = 0, g_hi = n_groups, g_step = gridDim.x, g_first = blockIdx.x;
+    if (gridDim.x >= 8) {                                   // one contiguous band of tile groups per XCD (halo rows stay in its L2)
+        const int xcd = blockIdx.x & 7;
+        const long chunk = (n_groups + 7) / 8;
+        g_lo = xcd * chunk;
+        g_hi = min(n_groups, g_lo + chunk);
+        g_step = (gridDim.x + 7 - xcd) >> 3;
+        g_first = g_lo + (blockIdx.x >> 3);
+    }
+    bool bad = false;
+    for (long grp = g_first; grp < g_hi; grp += g_step) {
+        const long tile = grp * tiles_per_block + lt;
+        if (tile >= n_tiles) break;
+        const int tx = (int)(tile % tiles_x);
+        const int ty = (int)((tile / tiles_x) % tiles_y);
+        const int b = (int)(tile / ((long)tiles_x * tiles_y));
+        const int oy0 = ty * T, ox0 = tx * TW;
+
+        f32x2 acc[T][TW][2];
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+#pragma unroll
+            for (int j = 0; j < TW; ++j) acc[i][j][0] = acc[i][j][1] = (f32x2){0.f, 0.f};
+
+        const unsigned xoff0 = (unsigned)(((long)b * H * W) * C * 4) + coff;
+        auto load_row = [&](int iy, uint2 (&rh)[PW], uint2 (&rl)[PW]) {
+            const int gy = oy0 - pt + iy;
+            const bool row_ok = (unsigned)gy < (unsigned)H;
+#pragma unroll
+            for (int q = 0; q < PW; ++q) {
+                const int gx = ox0 - pl + q;
+                const bool ok = row_ok & ((unsigned)gx < (unsigned)W);
+                const unsigned off = ok ? xoff0 + (unsigned)((gy * W + gx) * C * 4) : 0xFFFFFFE0u;
+                rh[q] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0));
+                rl[q] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rx, off + 16u, 0, 0));
+            }
+        };
+        auto mac_row = [&](int iy, const uint2 (&rh)[PW], const uint2 (&rl)[PW]) {
+            f32x2 xr[PW][2];
+#pragma unroll
+            for (int q = 0; q < PW; ++q) {
+                const f16x4 h = __builtin_bit_cast(f16x4, rh[q]), l = __builtin_bit_cast(f16x4, rl[q]);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    xr[q][e][0] = (float)h[2 * e] + (float)l[2 * e];
+                    xr[q][e][1] = (float)h[2 * e + 1] + (float)l[2 * e + 1];
+                }
+            }
+#pragma unroll
+            for (int oy = 0; oy < T; ++oy) {
+                const int r = iy - oy;                 // wave-uniform
+                if (r < 0 || r >= K) continue;
+                const float* wrow = wl + (r * K) * (cb_chunks * 4);
+                float4 w0 = *reinterpret_cast<const float4*>(wrow);
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    const int sn = s + 1 < K ? s + 1 : s;
+                    const float4 n0 = *reinterpret_cast<const float4*>(wrow + sn * (cb_chunks * 4));
+                    const f32x2 wv[2] = {{w0.x, w0.y}, {w0.z, w0.w}};
+#pragma unroll
+                    for (int ox = 0; ox < TW; ++ox)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) acc[oy][ox][e] = xr[ox + s][e] * wv[e] + acc[oy][ox][e];
+                    w0 = n0;
+                }
+            }
+        };
+        if constexpr (WHOLE) {
+            uint2 rh[P][PW], rl[P][PW];
+#pragma unroll
+            for (int iy = 0; iy < P; ++iy) load_row(iy, rh[iy], rl[iy]);
+#pragma unroll
+            for (int iy = 0; iy < P; ++iy) mac_row(iy, rh[iy], rl[iy]);
+        } else {
+            uint2 rh[PW], rl[PW];
+            load_row(0, rh, rl);
+#pragma unroll 1
+            for (int iy = 0; iy < P; ++iy) {
+                uint2 nh[PW], nl[PW];
+                load_row(iy + 1 < P ? iy + 1 : iy, nh, nl);
+                mac_row(iy, rh, rl);
+#pragma unroll
+                for (int q = 0; q < PW; ++q) {
+                    rh[q] = nh[q];
+                    rl[q] = nl[q];
+                }
+            }
+        }
+
+        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int oy = 0; oy < T; ++oy) {
+            const int gy = oy0 + oy;
+            if (gy >= Ho) break;
+#pragma unroll
+            for (int ox = 0; ox < TW; ++ox) {
+                const int gx = ox0 + ox;
+                if (gx >= Wo) break;
+                float v[4] = {acc[oy][ox][0][0] + bv.x, acc[oy][ox][0][1] + bv.y, acc[oy][ox][1][0] + bv.z, acc[oy][ox][1][1] + bv.w};
+                f16x4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = vip_act_strict(v[e], act);
+                    oh[e] = (f16)v[e];
+                    ol[e] = (f16)(v[e] - (float)oh[e]);
+                    bad |= !(fabsf(v[e]) <= VIP_H2_MAX);
+                }
+                char* dst = y + (((long)b * Ho + gy) * Wo + gx) * C * 4 + coff;
+                *reinterpret_cast<f16x4*>(dst) = oh;
+                *reinterpret_cast<f16x4*>(dst + 16) = ol;
+            }
+        }
+    }
+    if (bad && status) *status = VIP_H2_OVERFLOW;
+}
+
+template <int K, int T, int TW, bool WHOLE>
+int launch_tile_h2(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int pt, int pl, int Ho, int Wo,
+                   int act, int* status, hipStream_t s) {
+    const int C4 = C / 4;
+    int cb = C4 < 32 ? C4 : 32;                                  // 4-channel chunks per block: <= 128 channels
+    if (C4 % 24 == 0 && C4 % 32 != 0) cb = 24;                    // ConvNeXt widths 96/192/384/768
+    const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + T - 1) / T;
+    const long n_tiles = (long)B * tiles_x * tiles_y;
+    const int tiles_per_block = 256 / cb;
+    const int gyc = (C4 + cb - 1) / cb;
+    long gx = (n_tiles + tiles_per_block - 1) / tiles_per_block;
+    const long gx_cap = (256L * VIP_DW_BLOCKS_PER_CU + gyc - 1) / gyc;
+    if (gx > gx_cap) gx = gx_cap;
+    const size_t smem = (size_t)K * K * cb * 4 * sizeof(float);
+    hipLaunchKernelGGL((dwconv_tile_h2_kernel<K, T, TW, WHOLE>), dim3((unsigned)gx, (unsigned)gyc), dim3(256), smem, s, (const char*)x, w,
+                       bias, (char*)y, B, H, W, C, pt, pl, Ho, Wo, act, cb, tiles_x, tiles_y, n_tiles, 4L * B * H * W * C, status);
+    return vip_launch_status("vip_dwconv2d_nhwc_h2(tile)");
+}
+
 template <int K, int T, int TW, bool WHOLE>
 int launch_tile(const f16* x, const float* w, const float* bias, f16* y, int B, int H, int W, int C, int pt, int pl,
                 int Ho, int Wo, int act, hipStream_t s, float* partials = nullptr, int parts = 0) {
@@ -287,6 +455,18 @@ int vip_dwconv_tiled(const void* x, const float* w, const float* bias, void* y, 
 #define VIP_GO(KK, TT, WW, WH) return launch_tile<KK, TT, WW, WH>(xi, wi, bias, yo, B, H, W, C, pt, pl, Ho, Wo, act, s, partials, parts)
     // measured on the ensemble's layer shapes (tools/bench_dw.py): 3x3 wants the whole 4x6 patch in flight (+15-25 %
     // over row-at-a-time); 5x5 / 7x7 whole-patch variants spill, and their rows carry enough FMAs to cover a load
+    if (k == 3) VIP_GO(3, 2, 4, true);
+    if (k == 5) VIP_GO(5, 2, 2, false);
+    if (k == 7) VIP_GO(7, 2, 4, false);
+#undef VIP_GO
+    return 1;
+}
+
+// stride-1 fast path of vip_dwconv2d_nhwc_h2 (strict_ops.hip); returns 1 if the shape is not handled here
+int vip_dwconv_tiled_h2(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k, int pt, int pl, int Ho,
+                        int Wo, int act, int* status, hipStream_t s) {
+    if (4L * B * H * W * C >= 0xFFFFFFE0L || C % 8 != 0) return 1;
+#define VIP_GO(KK, TT, WW, WH) return launch_tile_h2<KK, TT, WW, WH>(x, w, bias, y, B, H, W, C, pt, pl, Ho, Wo, act, status, s)
     if (k == 3) VIP_GO(3, 2, 4, true);
     if (k == 5) VIP_GO(5, 2, 2, false);
     if (k == 7) VIP_GO(7, 2, 4, false);

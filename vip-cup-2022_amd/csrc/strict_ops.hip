@@ -8,8 +8,14 @@
 // Parameters (LayerNorm gamma / beta, depthwise filters, head matrices, the relative-position table) are fp32 in both.
 // Same reference call sites as the fp16 kernels they mirror (pointwise.hip, window_attn.hip, mhsa.hip).
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
+
+inline bool attn_h2_mfma_enabled() {
+    static const bool on = !(getenv("VIP_ATTN_H2_MFMA") && atoi(getenv("VIP_ATTN_H2_MFMA")) == 0);
+    return on;
+}
 
 inline unsigned sgrid(long total) {
     long g = (total + 255) / 256;
@@ -22,10 +28,12 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 
 // storage policies: ld / st of 4 consecutive logical elements i .. i+3 (i % 4 == 0) of a tensor whose element 0 is at `b`
 struct SF32 {
+    static constexpr bool MFMA_ATTN = false;
     static __device__ __forceinline__ f32x4 ld(const void* b, long i) { return *reinterpret_cast<const f32x4*>(static_cast<const float*>(b) + i); }
     static __device__ __forceinline__ void st(void* b, long i, f32x4 v, int*) { *reinterpret_cast<f32x4*>(static_cast<float*>(b) + i) = v; }
 };
 struct SH2 {
+    static constexpr bool MFMA_ATTN = true;
     static __device__ __forceinline__ f32x4 ld(const void* b, long i) { return h2_ld4(b, i); }
     static __device__ __forceinline__ void st(void* b, long i, f32x4 v, int* status) { h2_st4(b, i, v, status); }
 };
@@ -174,6 +182,72 @@ __global__ __launch_bounds__(256) void slayernorm_kernel(const void* __restrict_
             S::st(y, (long)row * C + c4 * 4, o, status);
         }
     }
+}
+
+// The packed storage's own LayerNorm: LPR lanes per row (a power of two, 8..64: narrow rows share a wave), a lane owns CPL 32-byte
+// groups (8 channels: one 16-byte load of the hi halves, one of the lo halves), the two row reductions are DPP adds inside 16-lane rows
+// (pointwise.hip's scheme).  Same arithmetic as above: fp32 mean, biased variance of the centred values, 1 / sqrt, fp32 gamma / beta.
+template <int CPL>
+__global__ __launch_bounds__(256) void h2_layernorm_kernel(const char* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, char* __restrict__ y, int rows, int C, int lpr,
+                                                           float eps, int* status) {
+    const int rows_per_block = 256 / lpr;
+    const int sub = threadIdx.x % lpr;
+    const int row = blockIdx.x * rows_per_block + threadIdx.x / lpr;
+    const bool row_ok = row < rows;
+    const int C8 = C >> 3;
+    float v[CPL][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c8 = sub + i * lpr;
+        U4H8 h, l;
+        h.u = l.u = make_uint4(0, 0, 0, 0);
+        if (row_ok && c8 < C8) {
+            const char* src = x + ((long)row * C + c8 * 8) * 4;
+            h.u = *reinterpret_cast<const uint4*>(src);
+            l.u = *reinterpret_cast<const uint4*>(src + 16);
+        }
+        h2_join8(h, l, v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[i][j];
+    }
+    sum = group_allreduce_sum(sum, lpr);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        if (sub + i * lpr < C8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[i][j] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    sq = group_allreduce_sum(sq, lpr);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c8 = sub + i * lpr;
+        if (row_ok && c8 < C8) {
+            float o[8];
+            const f32x4 g0 = ld4(gamma + c8 * 8), g1 = ld4(gamma + c8 * 8 + 4), b0 = ld4(beta + c8 * 8), b1 = ld4(beta + c8 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (v[i][j] - mean) * rstd * g0[j] + b0[j];
+                o[4 + j] = (v[i][4 + j] - mean) * rstd * g1[j] + b1[j];
+            }
+            U4H8 oh, ol;
+            h2_split8(o, oh, ol);
+            char* dst = y + ((long)row * C + c8 * 8) * 4;
+            *reinterpret_cast<uint4*>(dst) = oh.u;
+            *reinterpret_cast<uint4*>(dst + 16) = ol.u;
+            bad |= h2_overflows8(o);
+        }
+    }
+    if (bad && status) *status = VIP_H2_OVERFLOW;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -527,6 +601,26 @@ int layernorm_impl(const char* who, const void* x, const float* gamma, const flo
     VIP_REQUIRE(x && y && gamma && beta, VIP_ERR_BAD_ARG, "%s: null pointer", who);
     VIP_REQUIRE(rows > 0 && C > 0, VIP_ERR_BAD_ARG, "%s: non-positive dimension", who);
     S_ALIGNED(A, C);
+    if constexpr (S::MFMA_ATTN) {           // (the packed storage) rows up to 2048 channels: the lanes-per-row kernel
+        const int C8 = C / 8;
+        int lpr = 8;
+        while (lpr < 64 && lpr < C8) lpr <<= 1;
+        const int cpl8 = (C8 + lpr - 1) / lpr;
+        if (cpl8 <= 4) {
+            const int rpb = 256 / lpr;
+            dim3 grid8((rows + rpb - 1) / rpb);
+            hipStream_t s8 = (hipStream_t)stream;
+#define H2_LN(N) hipLaunchKernelGGL(h2_layernorm_kernel<N>, grid8, dim3(256), 0, s8, (const char*)x, gamma, beta, (char*)y, rows, C, lpr, eps, status)
+            switch (cpl8) {
+                case 1: H2_LN(1); break;
+                case 2: H2_LN(2); break;
+                case 3: H2_LN(3); break;
+                default: H2_LN(4); break;
+            }
+#undef H2_LN
+            return vip_launch_status(who);
+        }
+    }
     const int cpl = (C / 4 + 63) / 64;
     VIP_REQUIRE(cpl <= 16, VIP_ERR_UNSUPPORTED, "%s: C=%d too large (max 4096)", who, C);
     dim3 grid((rows + 3) / 4);
@@ -630,6 +724,12 @@ int window_attn_impl(const char* who, const void* qkv, const void* q_global, con
     SAttnArgs a{qkv, q_global, bias_table, out, B, Hp, Wp, C, heads, ws, nq, ws * ws, scale, status};
     const long items = (long)B * (Hp / ws) * (Wp / ws) * heads;
     VIP_REQUIRE(items < (1L << 31), VIP_ERR_UNSUPPORTED, "%s: too many work items", who);
+    if constexpr (S::MFMA_ATTN) {       // packed storage: the matrix-core kernel of attn_h2.hip (VIP_ATTN_H2_MFMA=0: the VALU kernel below)
+        if (attn_h2_mfma_enabled()) {
+            const int st = vip_window_attn_h2_mfma(qkv, q_global, bias_table, out, B, Hp, Wp, C, heads, ws, nq, scale, status, (hipStream_t)stream);
+            if (st != 1) return st;
+        }
+    }
     return launch_sattn<S, 32, true>(a, items, (hipStream_t)stream, who);
 }
 
@@ -639,6 +739,12 @@ int mhsa_impl(const char* who, const void* qkv, void* out, int B, int N, int D, 
     VIP_REQUIRE(B > 0 && N > 0 && D > 0 && heads > 0, VIP_ERR_BAD_ARG, "%s: non-positive dimension", who);
     VIP_REQUIRE(D == heads * 64, VIP_ERR_UNSUPPORTED, "%s: head_dim must be 64 (D=%d heads=%d)", who, D, heads);
     VIP_REQUIRE(N <= 256, VIP_ERR_UNSUPPORTED, "%s: N=%d tokens (max 256)", who, N);
+    if constexpr (S::MFMA_ATTN) {
+        if (attn_h2_mfma_enabled()) {
+            const int st = vip_mhsa_h2_mfma(qkv, out, B, N, D, heads, scale, status, (hipStream_t)stream);
+            if (st != 1) return st;
+        }
+    }
     SAttnArgs a{qkv, nullptr, nullptr, out, B, 0, 0, D, heads, 0, 3, N, scale, status};
     return launch_sattn<S, 64, false>(a, (long)B * heads, (hipStream_t)stream, who);
 }
@@ -716,6 +822,13 @@ extern "C" int vip_layernorm_h2(const void* x, const float* gamma, const float* 
 }
 extern "C" int vip_dwconv2d_nhwc_h2(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k, int stride,
                                     int pt, int pl, int Ho, int Wo, int act, int* status, void* stream) {
+    // stride 1: the register-tiled kernel of dwconv.hip (the fp16 path's scheme; VIP_DW_H2_TILE=0: the plain kernel below)
+    static const bool tiled = !(getenv("VIP_DW_H2_TILE") && atoi(getenv("VIP_DW_H2_TILE")) == 0);
+    if (tiled && stride == 1 && x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && Ho > 0 && Wo > 0 && pt >= 0 && pl >= 0 &&
+        (unsigned)act <= 4u && (long)(Ho - 1) - pt < H && (long)(Wo - 1) - pl < W) {
+        const int st = vip_dwconv_tiled_h2(x, w, bias, y, B, H, W, C, k, pt, pl, Ho, Wo, act, status, (hipStream_t)stream);
+        if (st != 1) return st;
+    }
     return dwconv_impl<SH2, 8>("vip_dwconv2d_nhwc_h2", x, w, bias, y, B, H, W, C, k, stride, pt, pl, Ho, Wo, act, status, stream);
 }
 extern "C" int vip_mul_h2(const void* a, const void* b, void* y, long rows, int C, int lda, int a_off, int ldb, int b_off, int ldy, int y_off,

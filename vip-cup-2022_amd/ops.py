@@ -708,6 +708,9 @@ def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual:
     return dense(dense(x, fc1, act=act), fc2, residual=residual)
 
 
+_SE_H2_FUSED = os.environ.get("VIP_SE_H2_FUSED", "1") != "0"
+
+
 def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmoid", split: bool = True) -> torch.Tensor:
     """``g = act2(fc2(act1(fc1(global_avgpool(x)))))`` -> the SPLIT gate [B, 2, fc2.cout] fp16 (``fp16(g)`` and
     ``fp16(g - fp16(g))``: a gate scales a whole channel map, so its rounding error would not average out over pixels),
@@ -716,8 +719,19 @@ def se_gate(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act1, act2="sigmo
     One launch (vip_se_gate_f16: a workgroup per image, matrix-vector products out of L2) when the two weight matrices
     are small - every image re-reads them, so for wide gates (ResNet-RS / ResNeSt: Cr = C/4) the pool + two batched
     GEMMs are cheaper and are used instead (the last one with the split epilogue)."""
-    if _kind(x, "se_gate.x") != "f16":    # STRICT: pool -> Dense -> Dense, the gate is a plain [B, C] in the activation storage
-        return dense(dense(global_avgpool(x), fc1, act=act1), fc2, act=act2)
+    kind = _kind(x, "se_gate.x")
+    if kind != "f16":    # STRICT: the gate is a plain [B, C] in the activation storage
+        B, Cc = x.shape[0], x.shape[-1]
+        if (kind == "h2" and _SE_H2_FUSED and fc1.kind == fc2.kind == "h2" and fc1.groups == fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1
+                and fc1.cin == Cc and fc2.cin == fc1.cout and Cc * fc1.cout + fc1.cout * fc2.cout <= 256 * 1024 and x.dim() == 4):
+            # one launch (vip_se_gate_h2: the fp16 path's one-workgroup-per-image kernel on the packed storage)
+            out = torch.empty((B, fc2.cout), dtype=PACKED, device=x.device)
+            st = _abi.lib().vip_se_gate_h2(_p(x), _p(fc1.w), _p(fc1.bias), 1.0 / fc1.h2_scale, _p(fc2.w), _p(fc2.bias), 1.0 / fc2.h2_scale,
+                                           _p(out), B, x.shape[1] * x.shape[2], Cc, Cc, fc1.cout, fc1.ldw, fc2.cout, fc2.ldw, _act(act1),
+                                           _act(act2), _p(h2_status()), _stream())
+            _abi.check(st, "vip_se_gate_h2")
+            return out
+        return dense(dense(global_avgpool(x), fc1, act=act1), fc2, act=act2)    # pool -> Dense -> Dense
     B, H, W, Cc = x.shape
     assert fc1.groups == 1 and fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1
     assert fc1.cin == Cc and fc2.cin == fc1.cout, (fc1.cin, Cc, fc2.cin, fc1.cout)

@@ -71,6 +71,8 @@ class KernelProfile:
 def kernel_family(name: str) -> str:
     """profiler record name (the kernel the C dispatcher reports) -> roofline family: the three instantiation groups of the
     pointwise-GEMM pipeline (direct / LDS-staged / im2col) are one family, as in the rocprofv3 summaries."""
+    if name.startswith("h2:"):                       # the same kernels instantiated for the packed strict storage
+        return "h2:" + kernel_family(name[3:])
     return "pwk_*" if name.startswith("pwk_") else name
 
 
