@@ -317,7 +317,7 @@ def test_load_model_variant_from_model_config(tmp_path, key, report, monkeypatch
     import json
     import subprocess
     import vipcup_amd  # noqa: F401
-    from vipcup_amd import ensemble, pipeline, zoo
+    from vipcup_amd import ensemble, ops, pipeline, zoo
     spec = zoo.MEMBERS[key]
     if key == "gcvit_tiny":
         # gcvit with first_strides=1 keeps the stem at /2, so the graph only closes at HALF the manifest's input size: the global-query
@@ -365,7 +365,7 @@ def test_load_model_variant_from_model_config(tmp_path, key, report, monkeypatch
     for mode in ("fast", "strict"):
         model = zoo.load_model(str(ckpt_dir / "0.h5"), precision=mode)
         assert model.first_strides == 1 and model.head_act == "default"       # softmax on two classes IS the default pairing
-        x = pipeline.decode_jpegs(raws).resized(hw, hw, dtype=torch.float32 if mode == "strict" else torch.float16)
+        x = pipeline.decode_jpegs(raws).resized(hw, hw, dtype=ops.act_dtype(mode))
         got = model.predict(x).float().cpu().numpy()
         assert got.shape == (3, 2) and np.allclose(got.sum(1), 1.0, atol=1e-5)
         d = np.abs(got - want).max()

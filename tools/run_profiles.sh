@@ -16,6 +16,15 @@ cp $(find $OUT/streams -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_st
 export VIP_STREAMS=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -- python3 $ARGS > $OUT/bench_serial.json 2> $OUT/bench_serial.err
 cp $(find $OUT/serial -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_serial.csv
+# 2b. the STRICT precision step (packed fp16-pair storage): serial and as timed                -> kernel_stats_strict{,_streams}.csv
+SARGS="bench.py --precision strict --steps 5 --warmup 2 --no-cpu-baseline --no-resident-leg --no-batch-sweep --distinct-batches 4"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/strict_serial -- python3 $SARGS > $OUT/bench_strict_serial.json 2> $OUT/bench_strict_serial.err
+cp $(find $OUT/strict_serial -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_strict.csv
+unset VIP_STREAMS
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/strict_streams -- python3 $SARGS > $OUT/bench_strict_streams.json 2> $OUT/bench_strict_streams.err
+cp $(find $OUT/strict_streams -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_strict_streams.csv
+rm -rf $OUT/strict_serial $OUT/strict_streams
+export VIP_STREAMS=1
 PMC_ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-resident-leg --no-strict-leg --no-batch-sweep --distinct-batches 2"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $PMC_ARGS > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $PMC_ARGS > $OUT/pmc_write.json 2> $OUT/pmc_write.err

@@ -22,6 +22,7 @@
 // kecam common_layers.py:190-248; tfimm convnext.py:260-267,320-327) and every Dense layer.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 // VIP_GEMM_H2 = 1 (conv_h2.hip includes this file a second time): the same kernels for the packed STRICT storage of common.hpp -
 // every operand element is an fp16 (hi, lo) pair, 8 channels = [hi x 8][lo x 8] = two 16-byte MFMA fragments.  Seen as halfs, a packed
@@ -81,29 +82,44 @@ struct ConvArgs {
 template <int ACT, bool RES, int POST>      // POST: 0 none, 1 ReLU, 2 run-time a.act_post
 __device__ __forceinline__ void h2_store8(const ConvArgs& a, const f32x4& q0, const f32x4& q1, unsigned off, unsigned roff,
                                           const __amdgpu_buffer_rsrc_t& rb_res, const __amdgpu_buffer_rsrc_t& rb_y) {
-    float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+    // two values per VALU slot (v_pk_mul / v_pk_fma / v_pk_add_f32): the GELU / swish epilogues of the many-pixel layers are VALU-bound
+    // otherwise.  Activations: the packed forms of common.hpp (hardware exp2 / rcp, erfc polynomial: <= 7e-7 absolute).
+    f32x2 p[4] = {{q0[0], q0[1]}, {q0[2], q0[3]}, {q1[0], q1[1]}, {q1[2], q1[3]}};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = vip_act_strict(v[j] * a.out_scale, ACT);
+    for (int e = 0; e < 4; ++e) p[e] = vip_act2<ACT>(p[e] * a.out_scale);
     if constexpr (RES) {
         U4H8 rh, rl;
         rh.u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rb_res, roff, 0, 0));
         rl.u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rb_res, roff + 16u, 0, 0));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)rh.e[j] + (float)rl.e[j];
+        for (int e = 0; e < 4; ++e)
+            p[e] += (f32x2){(float)rh.e[2 * e], (float)rh.e[2 * e + 1]} + (f32x2){(float)rl.e[2 * e], (float)rl.e[2 * e + 1]};
     }
     if constexpr (POST == 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        for (int e = 0; e < 4; ++e) p[e] = (f32x2){fmaxf(p[e].x, 0.f), fmaxf(p[e].y, 0.f)};
     } else if constexpr (POST == 2) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = vip_act_strict(v[j], a.act_post);
+        for (int e = 0; e < 4; ++e) p[e] = (f32x2){vip_act_strict(p[e].x, a.act_post), vip_act_strict(p[e].y, a.act_post)};
     }
     U4H8 oh, ol;
-    h2_split8(v, oh, ol);
+    f32x2 tot = {0.f, 0.f};
+    float mx = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const f16x2 h = __builtin_convertvector(p[e], f16x2);
+        const f32x2 d = p[e] - __builtin_convertvector(h, f32x2);
+        const f16x2 l = __builtin_convertvector(d, f16x2);
+        oh.e[2 * e] = h.x; oh.e[2 * e + 1] = h.y;
+        ol.e[2 * e] = l.x; ol.e[2 * e + 1] = l.y;
+        tot += p[e];                                     // a NaN or an Inf anywhere makes the sum non-finite (finite values cannot overflow it)
+        mx = fmaxf(mx, fmaxf(fabsf(p[e].x), fabsf(p[e].y)));
+    }
     typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh.u), rb_y, off, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol.u), rb_y, off + 16u, 0, 0);
-    if (a.status && off != OOB2 && h2_overflows8(v)) *a.status = VIP_H2_OVERFLOW;
+    const float ts = tot.x + tot.y;
+    if (a.status && off != OOB2 && (!(mx <= VIP_H2_MAX) || !(fabsf(ts) <= 3.0e38f))) *a.status = VIP_H2_OVERFLOW;
 }
 
 __device__ __forceinline__ int swz_x(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
@@ -853,19 +869,23 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
     // ~20 registers stay live through it (the loop is at the 256-VGPR limit of two waves per SIMD)
     int m_base = m0 + l15, n_lane = n0 + lq * 8;
     asm volatile("" : "+v"(m_base), "+v"(n_lane));
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int n_first = n_lane + g * 64;
+    // (not a loop over g: with the packed-storage epilogue inlined seven times the unroller gives up and the accumulators would be
+    // indexed dynamically, i.e. live in scratch)
+    auto epi = [&](auto gtag) {
+        constexpr int G_ = decltype(gtag)::value;
+        const int n_first = n_lane + G_ * 64;
         switch (mode) {
-            case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
         }
-    }
+    };
+    epi(std::integral_constant<int, 0>{});
+    if constexpr (NG > 1) epi(std::integral_constant<int, 1>{});
 }
 
 
@@ -1010,19 +1030,23 @@ __global__ __launch_bounds__(256, 3) void pwk_direct2_kernel(ConvArgs a, int mod
 
     int m_base = m0 + l15, n_lane = n0 + lq * 8;
     asm volatile("" : "+v"(m_base), "+v"(n_lane));
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int n_first = n_lane + g * 64;
+    // (not a loop over g: with the packed-storage epilogue inlined seven times the unroller gives up and the accumulators would be
+    // indexed dynamically, i.e. live in scratch)
+    auto epi = [&](auto gtag) {
+        constexpr int G_ = decltype(gtag)::value;
+        const int n_first = n_lane + G_ * 64;
         switch (mode) {
-            case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
         }
-    }
+    };
+    epi(std::integral_constant<int, 0>{});
+    if constexpr (NG > 1) epi(std::integral_constant<int, 1>{});
 }
 
 #endif  // VIP_BUILD_EXPERIMENTS
@@ -1253,19 +1277,23 @@ __global__ __launch_bounds__(256 * WN, WN == 1 ? 2 : 1) void pwk_gemm_kernel(Con
     // ~20 registers stay live through it (the loop is at the 256-VGPR limit of two waves per SIMD)
     int m_base = m0 + l15, n_lane = n0 + lq * 8;
     asm volatile("" : "+v"(m_base), "+v"(n_lane));
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int n_first = n_lane + g * 64;
+    // (not a loop over g: with the packed-storage epilogue inlined seven times the unroller gives up and the accumulators would be
+    // indexed dynamically, i.e. live in scratch)
+    auto epi = [&](auto gtag) {
+        constexpr int G_ = decltype(gtag)::value;
+        const int n_first = n_lane + G_ * 64;
         switch (mode) {
-            case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-            default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+            case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
         }
-    }
+    };
+    epi(std::integral_constant<int, 0>{});
+    if constexpr (NG > 1) epi(std::integral_constant<int, 1>{});
 }
 
 template <int NG, int PT>

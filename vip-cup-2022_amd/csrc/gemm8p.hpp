@@ -320,19 +320,23 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(ConvArgs a, int mode) {
             setup_tile(tile);
             issue_prologue();                               // every wave is past the k-loop's last barrier: no fragment read is pending
         }
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int n_first = n_lane + g * 64;
+        // (not a loop over g: with the packed-storage epilogue inlined seven times the unroller gives up and the accumulators would be
+        // indexed dynamically, i.e. live in scratch)
+        auto epi = [&](auto gtag) {
+            constexpr int G_ = decltype(gtag)::value;
+            const int n_first = n_lane + G_ * 64;
             switch (mode) {
-                case 1: pw_epilogue<4, VIP_ACT_RELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-                case 2: pw_epilogue<4, VIP_ACT_SILU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-                case 3: pw_epilogue<4, VIP_ACT_GELU, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-                case 4: pw_epilogue<4, VIP_ACT_SIGMOID, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-                case 5: pw_epilogue<4, VIP_ACT_NONE, true, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-                case 6: pw_epilogue<4, VIP_ACT_NONE, true, true>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
-                default: pw_epilogue<4, VIP_ACT_NONE, false, false>(a, acc[g], m_base, n_first, rb_res, rb_y); break;
+                case 1: pw_epilogue<4, VIP_ACT_RELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 2: pw_epilogue<4, VIP_ACT_SILU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 3: pw_epilogue<4, VIP_ACT_GELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 4: pw_epilogue<4, VIP_ACT_SIGMOID, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 5: pw_epilogue<4, VIP_ACT_NONE, true, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 6: pw_epilogue<4, VIP_ACT_NONE, true, true>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                default: pw_epilogue<4, VIP_ACT_NONE, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
             }
-        }
+        };
+        epi(std::integral_constant<int, 0>{});
+        if constexpr (2 > 1) epi(std::integral_constant<int, 1>{});
         if (!more) break;
     }
 #undef G8_DSR
