@@ -328,6 +328,13 @@ def main():
         peaks = {"mfma_tflops": PEAK_MFMA_F16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS}
         peaks.update(workloads.measure_peaks())
         roof = wl.roofline(peaks)
+        if roof is not None and any(m.startswith("gcvit") for m in wl.members) and len(wl.members) == 1:
+            # BASELINE config 3 / SURVEY 8(d): the north-star kernel's roofline per level and FLOP-weighted
+            lv = wl.attention_levels(peaks)
+            if lv is not None:
+                roof["levels"] = lv["levels"]
+                roof["flop_weighted"] = lv["flop_weighted"]
+                roof["levels_definition"] = lv["definition"]
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(wl, max(1, a.cpu_batches), max(1, a.cpu_batch), max(1, a.cpu_warm))

@@ -1041,7 +1041,8 @@ def window_attention(qkv, q_global, bias_table, heads: int, ws: int, scale: floa
         # (q, k, v read + out written) per (window, head)
         nwh = B * (Hp // ws) * (Wp // ws) * heads
         N = ws * ws
-        tok = _PROF.start("window_attn_kernel", nwh * 4.0 * N * N * 32, nwh * 4.0 * N * 32 * 2)
+        tok = _PROF.start("window_attn_kernel", nwh * 4.0 * N * N * 32, nwh * 4.0 * N * 32 * 2,
+                          f"attn core ws{ws} C={Cc} heads={heads} map={Hp}x{Wp} global={int(q_global is not None)}")
     st = _abi.lib().vip_window_attn_fwd_f16(_p(qkv), _p(q_global), _p(bias_table), _p(out), B, Hp, Wp, Cc, heads,
                                             ws, nq, float(scale), _stream())
     if tok is not None:
@@ -1084,7 +1085,8 @@ def gcvit_attn_block(x, q_global, ln, qkv: ConvWeight, proj: ConvWeight, bias_ta
         # the fused form of SURVEY.md section 8(d): per window 2 N C^2 (1 + nq) + 4 N^2 C FLOPs (= 8 N C^2 + 4 N^2 C with q, k, v) and
         # 4 N C bytes (x in, y out, fp16)
         nwin, N = B * (Hp // ws) * (Wp // ws), ws * ws
-        tok = _PROF.start("gcvit_attn_block_kernel", nwin * (2.0 * N * Cc * Cc * (1 + nq) + 4.0 * N * N * Cc), nwin * 4.0 * N * Cc)
+        tok = _PROF.start("gcvit_attn_block_kernel", nwin * (2.0 * N * Cc * Cc * (1 + nq) + 4.0 * N * N * Cc), nwin * 4.0 * N * Cc,
+                          f"attn block ws{ws} C={Cc} heads={heads} map={Hp}x{Wp} global={int(q_global is not None)}")
     st = _abi.lib().vip_gcvit_attn_block_f16(_p(x), _p(q_global), _p(ln[0]), _p(ln[1]), float(ln[2]), _p(qkv.w), qkv.ldw, _p(qkv.bias),
                                              _p(proj.w), proj.ldw, _p(proj.bias), _p(bias_table), _p(out), B, Hp, Wp, Cc, heads, ws,
                                              float(scale), _stream())

@@ -390,11 +390,18 @@ def load_tf_checkpoint(prefix: str) -> Dict[str, np.ndarray]:
     b = Bundle(prefix)
     names = b.object_graph_names()
     out: Dict[str, np.ndarray] = {}
+    unnamed = []
     for key, e in b.entries.items():
         if key == OBJECT_GRAPH_KEY or e.dtype == DT_STRING:
             continue
         if names:
-            if key not in names or "/.OPTIMIZER_SLOT/" in key or key.startswith(("optimizer/", "save_counter/")):
+            # bookkeeping that is not a model variable: optimizer state and slots, the save counter, and what Keras tracks under
+            # keras_api/ (metric totals / counts) - their un-prefixed names would also defeat the common-scope stripping of the caller
+            if ("/.OPTIMIZER_SLOT/" in key or key.startswith(("optimizer/", "save_counter/", "keras_api/")) or "/keras_api/" in key):
+                continue
+            if key not in names:
+                if key.endswith("/.ATTRIBUTES/VARIABLE_VALUE"):
+                    unnamed.append(key)              # a variable whose object-graph attribute carries no full_name
                 continue
             name = names[key]
         else:
@@ -403,6 +410,10 @@ def load_tf_checkpoint(prefix: str) -> Dict[str, np.ndarray]:
         if name in out:
             raise BundleError(f"{prefix}: two checkpoint entries map to the variable {name!r}")
         out[name] = b.tensor(key)
+    if unnamed:
+        # dropping them silently would surface later as "missing variable X" from a constructor, far from the cause
+        raise BundleError(f"{prefix}: {len(unnamed)} variable(s) have no name recorded in the object graph (full_name empty) and cannot be "
+                          f"mapped onto the member's Keras variables: {', '.join(sorted(unnamed)[:8])}{' ...' if len(unnamed) > 8 else ''}")
     if not out:
         raise BundleError(f"{prefix}: no variables found")
     return out

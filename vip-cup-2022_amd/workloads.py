@@ -237,6 +237,55 @@ class Workload:
         self._summ = fam
         return fam
 
+    def attention_levels(self, peaks: Dict[str, float]):
+        """the roofline of the GCViT window-attention kernel PER LEVEL and FLOP-weighted.  Every
+        attention launch of one instrumented step is grouped by its channel width (= level); a level served by the bare core
+        (`window_attn_kernel`) is priced with FLOPs 4 N^2 hd and bytes 4 N hd x 2 per (window, head) - intensity N / 2; a level served by
+        the fused LN -> qkv -> core -> proj block (`gcvit_attn_block_kernel`) with FLOPs 8 N C^2 + 4 N^2 C (6 N C^2 with a global query) and
+        bytes 4 N C per window - intensity ~2 C + N.  `achieved` = algorithmic FLOP / measured time, `ceiling` = min(P_mfma, I x BW_hbm)
+        with the vendor peaks, `frac` their ratio; `flop_weighted` weights the levels' fractions by the attention CORE's FLOPs (118 /
+        79 / 747 / 25 MFLOP per image for GCViT-Tiny), i.e. by where the north-star kernel's work is.  None without a GCViT member."""
+        prof = KernelProfile()
+        ops.set_profiler(prof)
+        try:
+            self.step(None if self.world == 1 else _NoExchange(), serial=True)
+        finally:
+            ops.set_profiler(None)
+        import re
+        levels: Dict[int, Dict] = {}
+        for fam, tag, n, ms, fl, by in prof.by_shape():
+            if fam not in ("window_attn_kernel", "gcvit_attn_block_kernel") or not tag:
+                continue
+            m = re.search(r"ws(\d+) C=(\d+) heads=(\d+) map=(\d+)x(\d+)", tag)
+            ws, C_, heads, Hp, Wp = (int(g) for g in m.groups())
+            d = levels.setdefault(C_, {"ws": ws, "C": C_, "heads": heads, "map": [Hp, Wp], "form": "fused block" if fam.startswith("gcvit") else "bare core",
+                                       "launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "core_flops": 0.0})
+            d["launches"] += n
+            d["ms"] += ms
+            d["flops"] += fl
+            d["bytes"] += by
+            N = ws * ws
+            d["core_flops"] += n * self.batch * (Hp // ws) * (Wp // ws) * heads * 4.0 * N * N * 32
+        if not levels:
+            return None
+        pk_t, pk_b = peaks["mfma_tflops"], peaks["hbm_gbs"]
+        out, wsum, wfrac = [], 0.0, 0.0
+        for i, C_ in enumerate(sorted(levels)):
+            d = levels[C_]
+            sec = d["ms"] * 1e-3
+            tf = d["flops"] / sec / 1e12
+            inten = d["flops"] / d["bytes"]
+            ceil = min(pk_t, inten * pk_b * 1e-3)
+            frac = tf / ceil
+            out.append({"level": i, "window": d["ws"], "C": C_, "heads": d["heads"], "form": d["form"], "launches": d["launches"],
+                        "avg_launch_us": d["ms"] / d["launches"] * 1e3, "achieved_tflops": tf, "algorithmic_gbs": d["bytes"] / sec / 1e9,
+                        "intensity_flop_per_byte": inten, "bound": "mfma" if ceil >= pk_t else "hbm", "ceiling_tflops": ceil, "frac": frac,
+                        "core_mflop_per_image": d["core_flops"] / (self.batch * self.world) / 1e6})
+            wsum += d["core_flops"]
+            wfrac += d["core_flops"] * frac
+        return {"levels": out, "flop_weighted": wfrac / wsum,
+                "definition": "SURVEY.md 8(d): per level achieved algorithmic TFLOP/s / min(P_mfma, I x BW_hbm); weights = attention-core FLOPs"}
+
     def roofline(self, peaks: Dict[str, float]):
         """``peaks`` = {"mfma_tflops", "hbm_gbs"} vendor figures + optional {"mfma_tflops_measured", "hbm_gbs_measured"}."""
         summ = getattr(self, "_summ", None) or self.profile()

@@ -251,6 +251,14 @@ def match_variable_names(spec: MemberSpec, params):
     scope is removed, remove it.  Anything else is left alone - the constructor then names the first missing variable."""
     if f"{spec.head}/kernel" in params:          # the classifier is where the graph expects it: nothing to do (and no synthesis cost)
         return params
+    from . import timm_names
+    if timm_names.looks_like_timm(params):
+        # a timm (PyTorch) state_dict saved as .npz - where the tfimm members' weights come from: mapped by the reference's own rule
+        # (tfimm/utils/timm.py:39-106) and re-laid-out (OIHW -> HWIO, Dense kernels transposed, :164-190)
+        template = {k: tuple(v.shape) for k, v in spec.synth(spec.seed).items()}
+        got = timm_names.from_timm_state_dict({k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in params.items()}, template)
+        got.pop("__unused__", None)
+        return {k: torch.from_numpy(v) for k, v in got.items()}
     want = set(spec.synth(spec.seed))
     if want <= set(params):
         return params
