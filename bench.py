@@ -361,7 +361,10 @@ def main():
         detail = {"kernel_families": wl.extra(), "resident_input_variant": resident, "strict_precision": strict,
                   "batch_sweep": sweep,
                   "peaks": {"vendor": {"mfma_f16_tflops": PEAK_MFMA_F16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS},
-                            "measured_on_box": {k: round(v, 1) for k, v in peaks.items() if k.endswith("_measured")}}}
+                            "measured_on_box": {k: (round(v, 1) if isinstance(v, float) else v) for k, v in peaks.items() if k.endswith("_measured")},
+                            "guide_achievable_hbm_gbs": 6290.0,
+                            "note": "peak_measured (HBM) = the best of three copy probes on THIS box (vip_microbench_copy_variant); "
+                                    "MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy"}}
         if world > 1:
             detail["shard_plan"] = wl.plan.describe()
         line["detail"] = detail

@@ -510,6 +510,9 @@ size_t vip_workspace_bytes(int op, const int64_t* dims, int ndims);
  * vip_microbench_mfma_f16: every wave of a chip-filling grid issues `iters` rounds of 16 independent
  * v_mfma_f32_16x16x32_f16; *flops_h receives the FLOPs of the launch; sink = >= 4 device bytes. */
 int vip_microbench_copy(const void* src, void* dst, size_t bytes, void* stream);
+/* the same probe in two more access shapes; bench.py reports the best of the three as `peak_measured`:
+ * variant 0 = vip_microbench_copy, 1 = flat float4 copy (one 16-byte element per thread), 2 = one contiguous 64 KiB span per workgroup */
+int vip_microbench_copy_variant(const void* src, void* dst, size_t bytes, int variant, void* stream);
 int vip_microbench_mfma_f16(void* sink, int iters, double* flops_h, void* stream);
 
 #ifdef __cplusplus

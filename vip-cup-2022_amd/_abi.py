@@ -119,6 +119,7 @@ SIGNATURES = {
     "vip_conv2d_kernel_name": (_i, [C.POINTER(ConvDesc), _i, _i, _i, C.c_char_p, _sz]),
     "vip_workspace_bytes": (_sz, [_i, C.POINTER(C.c_int64), _i]),
     "vip_microbench_copy": (_i, [_vp, _vp, _sz, _vp]),
+    "vip_microbench_copy_variant": (_i, [_vp, _vp, _sz, _i, _vp]),
     "vip_microbench_mfma_f16": (_i, [_vp, _i, C.POINTER(C.c_double), _vp]),
 }
 

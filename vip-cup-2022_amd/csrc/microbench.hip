@@ -22,6 +22,27 @@ __global__ __launch_bounds__(256) void copy16_kernel(const u32x4* __restrict__ s
     for (; i < n16; i += stride) dst[i] = src[i];
 }
 
+// variant 1: what MI355X_MICROARCH.md quotes 6.29 TB/s for - a plain float4 copy, one 16-byte element per thread, no loop
+__global__ __launch_bounds__(256) void copy16_flat_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+// variant 2: each workgroup streams ONE contiguous 64 KiB span (16 x 16 bytes per lane, all loads issued before the first store)
+__global__ __launch_bounds__(256) void copy16_span_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16) {
+    const size_t base = (size_t)blockIdx.x * 4096 + threadIdx.x;
+    u32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        v[u] = i < n16 ? src[i] : (u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n16) dst[i] = v[u];
+    }
+}
+
 constexpr int MFMA_PER_ROUND = 16;
 
 __global__ __launch_bounds__(256) void mfma_peak_kernel(float* sink, int iters) {
@@ -52,6 +73,27 @@ extern "C" int vip_microbench_copy(const void* src, void* dst, size_t bytes, voi
     VIP_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, VIP_ERR_ALIGNMENT, "vip_microbench_copy: 16-byte aligned pointers");
     hipLaunchKernelGGL(copy16_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, bytes / 16);
     return vip_launch_status("vip_microbench_copy");
+}
+
+/* the other copy probes (bench.py takes the best of the three as the box's achievable HBM rate): 0 = vip_microbench_copy's grid-stride
+ * non-temporal kernel, 1 = flat float4 copy (one element per thread: the form MI355X_MICROARCH.md's 6.29 TB/s is quoted for),
+ * 2 = one contiguous 64 KiB span per workgroup */
+extern "C" int vip_microbench_copy_variant(const void* src, void* dst, size_t bytes, int variant, void* stream) {
+    if (variant == 0) return vip_microbench_copy(src, dst, bytes, stream);
+    VIP_REQUIRE(src && dst && bytes >= 16 && bytes % 16 == 0, VIP_ERR_BAD_ARG, "vip_microbench_copy_variant: bytes must be a positive multiple of 16");
+    VIP_REQUIRE(((uintptr_t)src | (uintptr_t)dst) % 16 == 0, VIP_ERR_ALIGNMENT, "vip_microbench_copy_variant: 16-byte aligned pointers");
+    VIP_REQUIRE(variant == 1 || variant == 2, VIP_ERR_BAD_ARG, "vip_microbench_copy_variant: variant 0, 1 or 2");
+    const size_t n16 = bytes / 16;
+    if (variant == 1) {
+        const size_t blocks = (n16 + 255) / 256;
+        VIP_REQUIRE(blocks < (1ull << 31), VIP_ERR_UNSUPPORTED, "vip_microbench_copy_variant: buffer too large");
+        hipLaunchKernelGGL(copy16_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, n16);
+    } else {
+        const size_t blocks = (n16 + 4095) / 4096;
+        VIP_REQUIRE(blocks < (1ull << 31), VIP_ERR_UNSUPPORTED, "vip_microbench_copy_variant: buffer too large");
+        hipLaunchKernelGGL(copy16_span_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, (u32x4*)dst, n16);
+    }
+    return vip_launch_status("vip_microbench_copy_variant");
 }
 
 extern "C" int vip_microbench_mfma_f16(void* sink, int iters, double* flops_h, void* stream) {

@@ -94,6 +94,11 @@ class Workload:
             mine = sorted({m for ms in self.plan.units[rank].values() for m in ms})
             built = {m: zoo.build_member(members[m], precision=self.precision) for m in mine}   # only what this rank's plan names is resident
             models = [built.get(m, (zoo.MEMBERS[members[m]], None)) for m in range(len(members))]
+        else:
+            # members handed in (bench.py's hybrid path builds ALL of them for measure_costs): keep only what this rank's plan names, so
+            # that a rank does not hold every member's weights and buffers on top of a second precision's set
+            mine = {m for ms in self.plan.units[rank].values() for m in ms}
+            models = [mod if m in mine else (mod[0], None) for m, mod in enumerate(models)]
         self.models = models
         # synthetic batches (SURVEY.md section 8(d) generator), the same bytes for every image-shard: JPEG byte strings in host RAM
         if jpegs is None:
@@ -434,15 +439,22 @@ def measure_peaks(ms_budget: float = 50.0) -> Dict[str, float]:
         e1.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    t_copy = timed(lambda: _abi.check(lib.vip_microbench_copy(src.data_ptr(), dst.data_ptr(), nbytes, st), "vip_microbench_copy"),
-                   ms_budget)
+    # three access shapes of the same 1 GiB copy (grid-stride non-temporal, flat float4 - the form MI355X_MICROARCH.md's 6.29 TB/s is
+    # quoted for -, one 64 KiB span per workgroup): the best of them is what this box's HBM delivers to a streaming kernel
+    t_variants = {}
+    for variant in (0, 1, 2):
+        t_variants[variant] = timed(lambda v=variant: _abi.check(lib.vip_microbench_copy_variant(src.data_ptr(), dst.data_ptr(), nbytes, v, st),
+                                                                   "vip_microbench_copy_variant"), ms_budget / 2)
+    t_copy = min(t_variants.values())
     sink = torch.zeros((16,), dtype=torch.float32, device="cuda")
     flops = C.c_double(0.0)
     iters = 2000
     t_mfma = timed(lambda: _abi.check(lib.vip_microbench_mfma_f16(sink.data_ptr(), iters, C.byref(flops), st), "vip_microbench_mfma_f16"),
                    ms_budget)
     del src, dst
-    return {"hbm_gbs_measured": 2.0 * nbytes / (t_copy * 1e-3) / 1e9, "mfma_tflops_measured": flops.value / (t_mfma * 1e-3) / 1e12}
+    return {"hbm_gbs_measured": 2.0 * nbytes / (t_copy * 1e-3) / 1e9, "mfma_tflops_measured": flops.value / (t_mfma * 1e-3) / 1e12,
+            "hbm_gbs_by_probe_measured": {("grid_stride_nt", "flat_float4", "span_64k")[v]: round(2.0 * nbytes / (t * 1e-3) / 1e9, 1)
+                                          for v, t in t_variants.items()}}
 
 
 def member_list(name: str) -> List[str]:
