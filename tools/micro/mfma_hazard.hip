@@ -78,6 +78,81 @@ __global__ __launch_bounds__(256) void victim(unsigned* bad, int reps) {
                 "v_mov_b32 %0, v40\n"
                 : "=v"(got) : "v"(a), "v"(b), "n"(K), "v"(ldsaddr) : "v40", "v41", "v42", "v43");
             if (got != 7.0f) ++nbad;
+        } else if constexpr (TEST == 5 || TEST == 6) {
+            // WAR on an MFMA SOURCE operand: three independent MFMAs back to back share their B operand v[60:63] (the round-2 kernel's
+            // last QK MFMAs, old14.s lines 839-841, share the Q fragment v[14:17]), and the very next instruction OVERWRITES v60 -
+            // TEST 5 with a VALU write (there: v_add_u32 v14, ...), TEST 6 with an LDS load (there: ds_read2_b32 v[14:15]) - after
+            // s_nop K.  hipcc emits K = none: its hazard table has no entry "XDL read SrcA/B -> VALU / LDS write".  B = 1 -> 32.
+            if constexpr (TEST == 5)
+                asm volatile(
+                    "v_mov_b32 v60, %1\n v_mov_b32 v61, %1\n v_mov_b32 v62, %1\n v_mov_b32 v63, %1\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_mfma_f32_16x16x32_f16 v[40:43], %2, v[60:63], 0\n"
+                    "v_mfma_f32_16x16x32_f16 v[44:47], %2, v[60:63], 0\n"
+                    "v_mfma_f32_16x16x32_f16 v[48:51], %2, v[60:63], 0\n"
+                    "s_nop %3\n"
+                    "v_mov_b32 v60, 0x4d004d00\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_mov_b32 %0, v48\n"
+                    : "=v"(got) : "v"(0x3c003c00u), "v"(a), "n"(K), "v"(ldsaddr)
+                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v60", "v61", "v62", "v63");
+            else
+                asm volatile(
+                    "v_mov_b32 v60, %1\n v_mov_b32 v61, %1\n v_mov_b32 v62, %1\n v_mov_b32 v63, %1\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_mfma_f32_16x16x32_f16 v[40:43], %2, v[60:63], 0\n"
+                    "v_mfma_f32_16x16x32_f16 v[44:47], %2, v[60:63], 0\n"
+                    "v_mfma_f32_16x16x32_f16 v[48:51], %2, v[60:63], 0\n"
+                    "s_nop %3\n"
+                    "ds_read_b32 v60, %4\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_mov_b32 %0, v48\n"
+                    : "=v"(got) : "v"(0x3c003c00u), "v"(a), "n"(K), "v"(ldsaddr)
+                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v60", "v61", "v62", "v63");
+            if (got != 32.0f) ++nbad;
+        } else if constexpr (TEST == 3 || TEST == 4) {
+            // the round-2 window-attention kernel's own instruction sequence (hipcc's output, /tmp/race/old14.s lines 812-820 of the
+            // ws 14 kernel): two independent MFMAs, the first one's result consumed by v_pk_add_f32 after
+            // [ds_read2_b32, s_mov, s_mov, v_mfma, v_lshrrev, s_waitcnt, s_nop K].  TEST 3: in place (vDst = SrcA, as compiled);
+            // TEST 4: vDst in registers of its own.  A = B = 1 -> 32; table value 7 -> expect 39.
+            if constexpr (TEST == 3)
+                asm volatile(
+                    "v_mov_b32 v40, %1\n v_mov_b32 v41, %1\n v_mov_b32 v42, %1\n v_mov_b32 v43, %1\n"
+                    "v_mov_b32 v44, %1\n v_mov_b32 v45, %1\n v_mov_b32 v46, %1\n v_mov_b32 v47, %1\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_mfma_f32_16x16x32_f16 v[40:43], v[40:43], %2, 0\n"
+                    "ds_read2_b32 v[50:51], %4 offset1:1\n"
+                    "s_mov_b32 s20, 0xf149f2ca\n"
+                    "s_mov_b32 s21, s20\n"
+                    "v_mfma_f32_16x16x32_f16 v[44:47], v[44:47], %2, 0\n"
+                    "v_lshrrev_b32 v52, 2, v52\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "s_nop %3\n"
+                    "v_pk_add_f32 v[48:49], v[40:41], v[50:51]\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "v_mov_b32 %0, v48\n"
+                    : "=v"(got) : "v"(0x3c003c00u), "v"(b), "n"(K), "v"(ldsaddr)
+                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "s20", "s21");
+            else
+                asm volatile(
+                    "v_mov_b32 v40, 0\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"
+                    "v_mov_b32 v44, 0\n v_mov_b32 v45, 0\n v_mov_b32 v46, 0\n v_mov_b32 v47, 0\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_mfma_f32_16x16x32_f16 v[40:43], %1, %2, 0\n"
+                    "ds_read2_b32 v[50:51], %4 offset1:1\n"
+                    "s_mov_b32 s20, 0xf149f2ca\n"
+                    "s_mov_b32 s21, s20\n"
+                    "v_mfma_f32_16x16x32_f16 v[44:47], %1, %2, 0\n"
+                    "v_lshrrev_b32 v52, 2, v52\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "s_nop %3\n"
+                    "v_pk_add_f32 v[48:49], v[40:41], v[50:51]\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "v_mov_b32 %0, v48\n"
+                    : "=v"(got) : "v"(a), "v"(b), "n"(K), "v"(ldsaddr)
+                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "s20", "s21");
+            if (got != 39.0f) ++nbad;
         } else {
             asm volatile(
                 "v_mov_b32 v40, 0\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"
@@ -119,29 +194,37 @@ void launch_all(unsigned* bad, int reps, hipStream_t s) {
 int main() {
     unsigned* bad;
     float* sink;
-    CHECK(hipMalloc(&bad, 48 * 4));
+    CHECK(hipMalloc(&bad, 112 * 4));
     CHECK(hipMalloc(&sink, 64));
     hipStream_t sa, sb;
     CHECK(hipStreamCreate(&sa));
     CHECK(hipStreamCreate(&sb));
     const int reps = 200;
-    const char* names[3] = {"RAW  mfma -> s_nop K -> v_mov (VALU read of the result)          ",
+    const char* names[7] = {"RAW  mfma -> s_nop K -> v_mov (VALU read of the result)          ",
                             "WAW  mfma -> s_nop K -> ds_read into its vDst -> (long wait) -> read",
-                            "PAIR mfma (C = 0) -> s_nop K -> v_pk_add_f32 on the result           "};
+                            "PAIR mfma (C = 0) -> s_nop K -> v_pk_add_f32 on the result           ",
+                            "OLD  the round-2 kernel's sequence, vDst = SrcA (hipcc emitted K = 1)",
+                            "OLD' the same with vDst in registers of its own                      ",
+                            "WARv 3 mfma sharing SrcB -> s_nop K -> VALU write to SrcB's register  ",
+                            "WARl 3 mfma sharing SrcB -> s_nop K -> ds_read into SrcB's register   "};
     const int ks[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 15};
     for (int pass = 0; pass < 2; ++pass) {
-        CHECK(hipMemset(bad, 0, 48 * 4));
+        CHECK(hipMemset(bad, 0, 112 * 4));
         if (pass == 1)      // 4096 blocks x 4 waves of back-to-back MFMAs: several waves per SIMD for the whole victim run
             hipLaunchKernelGGL(mfma_hog, dim3(4096), dim3(256), 0, sb, sink, 60000);
         launch_all<0>(bad, reps, sa);
         launch_all<1>(bad, reps, sa);
         launch_all<2>(bad, reps, sa);
+        launch_all<3>(bad, reps, sa);
+        launch_all<4>(bad, reps, sa);
+        launch_all<5>(bad, reps, sa);
+        launch_all<6>(bad, reps, sa);
         CHECK(hipStreamSynchronize(sa));
-        std::vector<unsigned> h(48);
-        CHECK(hipMemcpy(h.data(), bad, 48 * 4, hipMemcpyDeviceToHost));
+        std::vector<unsigned> h(112);
+        CHECK(hipMemcpy(h.data(), bad, 112 * 4, hipMemcpyDeviceToHost));
         CHECK(hipDeviceSynchronize());
         printf("== %s (mismatches of %ld lane-results per cell)\n", pass ? "NEXT TO the MFMA-saturating kernel" : "alone", 1024L * 256 * reps);
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < 7; ++t) {
             printf("%s :", names[t]);
             for (int i = 0; i < 12; ++i) printf(" K=%d:%u", ks[i], h[t * 16 + ks[i]]);
             printf("\n");
