@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void mfma_hog(float* sink, int iters) {
 
 template <int TEST, int K>
 __global__ __launch_bounds__(256) void victim(unsigned* bad, int reps) {
-    __shared__ float lds[64];
-    lds[threadIdx.x & 63] = 7.0f;
+    __shared__ float lds[66];
+    if (threadIdx.x < 66) lds[threadIdx.x] = (TEST >= 7 && TEST != 10 && TEST != 11) ? 7.0f + 2.0f * (float)(threadIdx.x & 1) : 7.0f;
     __syncthreads();
     f16x8 a, b;
     for (int i = 0; i < 8; ++i) a[i] = b[i] = (_Float16)1.0f;
@@ -78,6 +78,106 @@ __global__ __launch_bounds__(256) void victim(unsigned* bad, int reps) {
                 "v_mov_b32 %0, v40\n"
                 : "=v"(got) : "v"(a), "v"(b), "n"(K), "v"(ldsaddr) : "v40", "v41", "v42", "v43");
             if (got != 7.0f) ++nbad;
+        } else if constexpr (TEST == 12 || TEST == 13) {
+            // the kernel's inner pattern, 16 times back to back, no MFMA in the victim: address VALU -> ds_read2_b32 INTO the address
+            // register pair -> wait -> v_pk_add_f32 accumulating the returned pair, half-swapped (12) or in natural order (13)
+#define HZ_STEP_SW "v_add_u32 v14, 0, %1\n ds_read2_b32 v[14:15], v14 offset1:1\n s_waitcnt lgkmcnt(0)\n v_pk_add_f32 v[40:41], v[40:41], v[14:15] op_sel:[0,1] op_sel_hi:[1,0]\n"
+#define HZ_STEP_NO "v_add_u32 v14, 0, %1\n ds_read2_b32 v[14:15], v14 offset1:1\n s_waitcnt lgkmcnt(0)\n v_pk_add_f32 v[40:41], v[40:41], v[14:15]\n"
+            const float odd = 7.0f + 2.0f * (float)((threadIdx.x + 1) & 1), even = 7.0f + 2.0f * (float)(threadIdx.x & 1);
+            if constexpr (TEST == 12)
+                asm volatile("v_mov_b32 v40, 0\n v_mov_b32 v41, 0\n s_nop %2\n"
+                             HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW
+                             HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW HZ_STEP_SW
+                             "s_nop 15\n v_mov_b32 %0, v40\n"
+                             : "=v"(got) : "v"(ldsaddr), "n"(K) : "v14", "v15", "v40", "v41");
+            else
+                asm volatile("v_mov_b32 v40, 0\n v_mov_b32 v41, 0\n s_nop %2\n"
+                             HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO
+                             HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO HZ_STEP_NO
+                             "s_nop 15\n v_mov_b32 %0, v40\n"
+                             : "=v"(got) : "v"(ldsaddr), "n"(K) : "v14", "v15", "v40", "v41");
+            if (got != 16.0f * (TEST == 12 ? odd : even)) ++nbad;
+        } else if constexpr (TEST == 10 || TEST == 11) {
+            // THE PAIR the failing ISA shows everywhere (tools/repro variant 1, ws 14 kernel):
+            //     v_pk_add_f32 v[114:115], v[24:25], v[14:15] op_sel:[0,1] op_sel_hi:[1,0]
+            //     v_add_u32_e32 v14, 0x8e40, v60          <- plain VALU WRITE to a source register of the packed add just issued
+            // TEST 10: v_pk_add_f32 reading v[50:51], then s_nop K, then v_mov_b32 v50 / v51 <- garbage.  TEST 11: the same with two scalar
+            // v_add_f32 (control).  No MFMA in the victim at all: the only matrix work on the SIMD is the co-runner's.
+            if constexpr (TEST == 10)
+                asm volatile(
+                    "v_mov_b32 v40, 32.0\n v_mov_b32 v41, 32.0\n v_mov_b32 v50, 7.0\n v_mov_b32 v51, 7.0\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "v_pk_add_f32 v[48:49], v[40:41], v[50:51] op_sel:[0,1] op_sel_hi:[1,0]\n"
+                    "s_nop %1\n"
+                    "v_mov_b32 v50, 0x8e40\n"
+                    "v_mov_b32 v51, 0x8e44\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_add_f32 %0, v48, v49\n"
+                    : "=v"(got) : "n"(K) : "v40", "v41", "v48", "v49", "v50", "v51");
+            else
+                asm volatile(
+                    "v_mov_b32 v40, 32.0\n v_mov_b32 v41, 32.0\n v_mov_b32 v50, 7.0\n v_mov_b32 v51, 7.0\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "v_add_f32 v48, v40, v51\n"
+                    "v_add_f32 v49, v41, v50\n"
+                    "s_nop %1\n"
+                    "v_mov_b32 v50, 0x8e40\n"
+                    "v_mov_b32 v51, 0x8e44\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_add_f32 %0, v48, v49\n"
+                    : "=v"(got) : "n"(K) : "v40", "v41", "v48", "v49", "v50", "v51");
+            if (got != 78.0f) ++nbad;
+        } else if constexpr (TEST >= 7 && TEST <= 9) {
+            // what the bisect of the real kernel points at (tools/repro: scalar adds or table values read BEFORE the MFMAs cure it, 64 idle
+            // cycles after the MFMAs do not): v_pk_add_f32 with a HALF-SWAPPED source (op_sel:[0,1] op_sel_hi:[1,0] - hipcc's way of
+            // using the two floats one ds_read2_b32 returned in reversed order) on a register pair that has just come back from LDS.
+            //   TEST 7: MFMA result + fresh LDS pair, half-swapped      TEST 8: constant + fresh LDS pair, half-swapped, an unrelated MFMA
+            //   in flight      TEST 9: TEST 7 without the swap.  lds[j] = 7 + 2 (j & 1): lo result = 32 + lds[lane + 1] (swapped) / lds[lane].
+            const float odd = 7.0f + 2.0f * (float)((threadIdx.x + 1) & 1), even = 7.0f + 2.0f * (float)(threadIdx.x & 1);
+            if constexpr (TEST == 7)
+                asm volatile(
+                    "v_mov_b32 v40, 0\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_mfma_f32_16x16x32_f16 v[40:43], %1, %2, 0\n"
+                    "v_mfma_f32_16x16x32_f16 v[44:47], %1, %2, 0\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "ds_read2_b32 v[50:51], %4 offset1:1\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "s_nop %3\n"
+                    "v_pk_add_f32 v[48:49], v[40:41], v[50:51] op_sel:[0,1] op_sel_hi:[1,0]\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "v_mov_b32 %0, v48\n"
+                    : "=v"(got) : "v"(a), "v"(b), "n"(K), "v"(ldsaddr)
+                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");
+            else if constexpr (TEST == 8)
+                asm volatile(
+                    "v_mov_b32 v40, 32.0\n v_mov_b32 v41, 32.0\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "v_mfma_f32_16x16x32_f16 v[44:47], %1, %2, 0\n"
+                    "ds_read2_b32 v[50:51], %4 offset1:1\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "s_nop %3\n"
+                    "v_pk_add_f32 v[48:49], v[40:41], v[50:51] op_sel:[0,1] op_sel_hi:[1,0]\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "v_mov_b32 %0, v48\n"
+                    : "=v"(got) : "v"(a), "v"(b), "n"(K), "v"(ldsaddr)
+                    : "v40", "v41", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");
+            else
+                asm volatile(
+                    "v_mov_b32 v40, 0\n v_mov_b32 v41, 0\n v_mov_b32 v42, 0\n v_mov_b32 v43, 0\n"
+                    "s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15\n"
+                    "v_mfma_f32_16x16x32_f16 v[40:43], %1, %2, 0\n"
+                    "v_mfma_f32_16x16x32_f16 v[44:47], %1, %2, 0\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "ds_read2_b32 v[50:51], %4 offset1:1\n"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    "s_nop %3\n"
+                    "v_pk_add_f32 v[48:49], v[40:41], v[50:51]\n"
+                    "s_nop 15\n s_nop 15\n"
+                    "v_mov_b32 %0, v48\n"
+                    : "=v"(got) : "v"(a), "v"(b), "n"(K), "v"(ldsaddr)
+                    : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51");
+            if (got != 32.0f + (TEST == 9 ? even : odd)) ++nbad;
         } else if constexpr (TEST == 5 || TEST == 6) {
             // WAR on an MFMA SOURCE operand: three independent MFMAs back to back share their B operand v[60:63] (the round-2 kernel's
             // last QK MFMAs, old14.s lines 839-841, share the Q fragment v[14:17]), and the very next instruction OVERWRITES v60 -
@@ -194,22 +294,29 @@ void launch_all(unsigned* bad, int reps, hipStream_t s) {
 int main() {
     unsigned* bad;
     float* sink;
-    CHECK(hipMalloc(&bad, 112 * 4));
+    CHECK(hipMalloc(&bad, 224 * 4));
     CHECK(hipMalloc(&sink, 64));
     hipStream_t sa, sb;
     CHECK(hipStreamCreate(&sa));
     CHECK(hipStreamCreate(&sb));
     const int reps = 200;
-    const char* names[7] = {"RAW  mfma -> s_nop K -> v_mov (VALU read of the result)          ",
+    const char* names[14] = {"RAW  mfma -> s_nop K -> v_mov (VALU read of the result)          ",
                             "WAW  mfma -> s_nop K -> ds_read into its vDst -> (long wait) -> read",
                             "PAIR mfma (C = 0) -> s_nop K -> v_pk_add_f32 on the result           ",
                             "OLD  the round-2 kernel's sequence, vDst = SrcA (hipcc emitted K = 1)",
                             "OLD' the same with vDst in registers of its own                      ",
                             "WARv 3 mfma sharing SrcB -> s_nop K -> VALU write to SrcB's register  ",
-                            "WARl 3 mfma sharing SrcB -> s_nop K -> ds_read into SrcB's register   "};
+                            "WARl 3 mfma sharing SrcB -> s_nop K -> ds_read into SrcB's register   ",
+                            "SWAP mfma result + fresh ds_read2 pair, v_pk_add_f32 half-swapped     ",
+                            "SWAPc constant + fresh ds_read2 pair, half-swapped, mfma in flight    ",
+                            "NOSW mfma result + fresh ds_read2 pair, v_pk_add_f32 plain            ",
+                            "PKWAR v_pk_add_f32 -> s_nop K -> plain VALU write to its SOURCE pair   ",
+                            "SCWAR two v_add_f32 -> s_nop K -> plain VALU write to their sources    ",
+                            "LOOPs 16 x [addr; ds_read2 into addr pair; wait; v_pk_add_f32 SWAPPED]",
+                            "LOOPn 16 x [addr; ds_read2 into addr pair; wait; v_pk_add_f32 plain]  "};
     const int ks[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 15};
     for (int pass = 0; pass < 2; ++pass) {
-        CHECK(hipMemset(bad, 0, 112 * 4));
+        CHECK(hipMemset(bad, 0, 224 * 4));
         if (pass == 1)      // 4096 blocks x 4 waves of back-to-back MFMAs: several waves per SIMD for the whole victim run
             hipLaunchKernelGGL(mfma_hog, dim3(4096), dim3(256), 0, sb, sink, 60000);
         launch_all<0>(bad, reps, sa);
@@ -219,12 +326,19 @@ int main() {
         launch_all<4>(bad, reps, sa);
         launch_all<5>(bad, reps, sa);
         launch_all<6>(bad, reps, sa);
+        launch_all<7>(bad, reps, sa);
+        launch_all<8>(bad, reps, sa);
+        launch_all<9>(bad, reps, sa);
+        launch_all<10>(bad, reps, sa);
+        launch_all<11>(bad, reps, sa);
+        launch_all<12>(bad, reps, sa);
+        launch_all<13>(bad, reps, sa);
         CHECK(hipStreamSynchronize(sa));
-        std::vector<unsigned> h(112);
-        CHECK(hipMemcpy(h.data(), bad, 112 * 4, hipMemcpyDeviceToHost));
+        std::vector<unsigned> h(224);
+        CHECK(hipMemcpy(h.data(), bad, 224 * 4, hipMemcpyDeviceToHost));
         CHECK(hipDeviceSynchronize());
         printf("== %s (mismatches of %ld lane-results per cell)\n", pass ? "NEXT TO the MFMA-saturating kernel" : "alone", 1024L * 256 * reps);
-        for (int t = 0; t < 7; ++t) {
+        for (int t = 0; t < 14; ++t) {
             printf("%s :", names[t]);
             for (int i = 0; i < 12; ++i) printf(" K=%d:%u", ks[i], h[t * 16 + ks[i]]);
             printf("\n");

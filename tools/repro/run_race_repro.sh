@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/../.." || exit 1
 P=vip-cup-2022_amd
 mkdir -p $P/variants
-for V in 0 1 3 4 5; do
+for V in ${RACE_VARIANTS:-0 1 3 4 5 6 7 8}; do
   OBJ=/tmp/wa_r2_$V.o
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -I$P/csrc -Wno-unused-result -ffp-contract=fast \
       -DVIP_BUILD_EXPERIMENTS=0 -DRACE_VARIANT=$V -x hip -c tools/repro/window_attn_round2.hip -o $OBJ 2>/dev/null || { echo "variant $V: build failed"; continue; }

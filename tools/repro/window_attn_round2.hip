@@ -6,6 +6,9 @@
 //   RACE_VARIANT 3  two scalar v_add_f32 instead of the packed add
 //   RACE_VARIANT 4  ALL table values read into registers and waited for BEFORE the first MFMA (C still 0), packed adds afterwards
 //   RACE_VARIANT 5  accumulators pinned (asm barrier) after the MFMAs and again after the adds: no register of a result is reused early
+//   RACE_VARIANT 6  s_waitcnt lgkmcnt(0) in front of every packed add (no counted LDS waits in the bias section)
+//   RACE_VARIANT 7  s_nop 7 + scheduling fence AFTER every packed add (nothing may touch its source registers for 8 cycles)
+//   RACE_VARIANT 8  the two table values of a pair loaded by two ds_read_b32 into a register pair in NATURAL order (no op_sel swap)
 #ifndef RACE_VARIANT
 #define RACE_VARIANT 0
 #endif
@@ -159,9 +162,23 @@ __device__ __forceinline__ void win_query_tile(const WinArgs& a, const U4H8& qfr
                 acc[t][r + 1] = __fadd_rn(acc[t][r + 1], bv.y);
                 asm volatile("" : "+v"(acc[t][r]), "+v"(acc[t][r + 1]));      // keep the two adds scalar
 #else
+#if RACE_VARIANT == 6
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#if RACE_VARIANT == 8
+                f32x2 bn = bv;
+                asm volatile("" : "+v"(bn));                                  // a register pair of its own, in natural order
+                const f32x2 sv = (f32x2){acc[t][r], acc[t][r + 1]} + bn;
+#else
                 const f32x2 sv = (f32x2){acc[t][r], acc[t][r + 1]} + bv;   // v_pk_add_f32
+#endif
                 acc[t][r] = sv.x;
                 acc[t][r + 1] = sv.y;
+#if RACE_VARIANT == 7
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#endif
 #endif
             }
         }

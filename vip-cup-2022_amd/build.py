@@ -30,6 +30,12 @@ def _sources():
                   if f.endswith((".hip", ".cpp")) and (EXPERIMENTS or f not in EXPERIMENT_SOURCES))
 
 
+# Per-file flags.  -fno-slp-vectorize: in these two files hipcc's SLP vectoriser pairs scalar fp32 operations into packed VALU ops with
+# half-SWAPPED sources (v_pk_*_f32 ... op_sel:[1,0] ...) - the instruction form behind the round-2 window-attention failure next to
+# MFMA-heavy co-runners (tools/repro/); nothing in them is VALU-bound, and tools/isa_lint.py (a CPU test) keeps every
+# shipped kernel free of that form.
+EXTRA_FLAGS = {"se_gate.hip": ["-fno-slp-vectorize"], "jpeg_pipeline.hip": ["-fno-slp-vectorize"]}
+
 # sources that #include another SOURCE file (one kernel family, two arithmetic modes)
 INCLUDES_SOURCE = {"conv_h2.hip": ["conv_igemm.hip"]}
 
@@ -46,7 +52,7 @@ def _compile(src, force):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= _deps_mtime(src)):
         return obj
-    cmd = [HIPCC, *CXXFLAGS, "-x", "hip", "-c", src, "-o", obj]
+    cmd = [HIPCC, *CXXFLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), "-x", "hip", "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -118,7 +118,9 @@ __device__ __forceinline__ void h2_store8(const ConvArgs& a, const f32x4& q0, co
     typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh.u), rb_y, off, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol.u), rb_y, off + 16u, 0, 0);
-    const float ts = tot.x + tot.y;
+    float tx = tot.x, ty = tot.y;
+    asm volatile("" : "+v"(tx), "+v"(ty));       // two scalars: hipcc otherwise forms the horizontal sum as a half-SWAPPED v_pk_add_f32
+    const float ts = tx + ty;                    // (op_sel:[0,1] op_sel_hi:[1,0]) - the form tools/isa_lint.py keeps out of the library
     if (a.status && off != OOB2 && (!(mx <= VIP_H2_MAX) || !(fabsf(ts) <= 3.0e38f))) *a.status = VIP_H2_OVERFLOW;
 }
 
