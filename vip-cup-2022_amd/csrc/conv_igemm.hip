@@ -611,7 +611,12 @@ int launch_pw(const ConvArgs& a, int mode, hipStream_t s) {
         if (a.w_lo) return launch_pw<KS, PT, true>(a, mode, s);
     }
     constexpr bool PRE = KS <= 3;
-    constexpr int LDS_MAX = 72 * 1024;               // two workgroups per CU
+    // two workgroups per CU.  H2: a packed weight slice is twice as large, so the same budget cuts N into more channel chunks and
+    // every chunk re-reads the activations; with >= 512K rows that traffic costs more than the second resident workgroup gains
+    // (M=2.5M N=384 K=96: 1.71 -> 1.23 ms), below that the shorter launch prefers the two workgroups (M=160K N=512 K=128:
+    // 0.16 vs 0.20 ms) - profiles/r04_ab_pw_h2_lds.log.  VIP_PW_H2_LDS_KB overrides.
+    static const int h2_lds_kb = getenv("VIP_PW_H2_LDS_KB") ? atoi(getenv("VIP_PW_H2_LDS_KB")) : 0;
+    const int LDS_MAX = (H2 ? (h2_lds_kb ? h2_lds_kb : (a.M >= (1 << 19) ? 156 : 72)) : 72) * 1024;
     // row stride in 16-byte chunks == 2 (mod 4), i.e. 32 (mod 64) bytes: ds_read_b128 is serviced in the lane groups
     // {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... over 64 banks, and with the fragment pattern (lane&15 = row, lane>>4 =
     // chunk) that stride puts each group's 16 chunks on 16 distinct 16-byte slots (an ODD chunk stride does not: 46 %
@@ -636,7 +641,7 @@ int launch_pw(const ConvArgs& a, int mode, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_kernel<KS, PT, PRE, HILO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL((pw_gemm_kernel<KS, PT, PRE, HILO>), dim3((unsigned)gx, (unsigned)n_chunks), dim3(256),
