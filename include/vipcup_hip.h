@@ -406,6 +406,22 @@ int vip_conv2d_kernel_name_h2(const vip_conv_desc* d, int has_residual, char* na
  * gamma / beta, depthwise filters, head matrices, relative-position table) and fp32 head outputs as there */
 int vip_dwconv2d_nhwc_h2(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k, int stride,
                          int pt, int pl, int Ho, int Wo, int act, int* status, void* stream);
+/* Stride-1 k = 3 / 5 / 7 DepthwiseConv2D on the packed storage, staged through LDS (dwconv_lds_h2.hip) - the Keras DepthwiseConv2D of
+ * tfimm's ConvNeXtBlock (/root/reference/models/tfimm/architectures/convnext.py:200-229) and of the MBConv blocks in strict mode.
+ * w_quad: the filter QUAD-MAJOR, fp32 [C/4][k*k][4] (vip_dw_filter_quad_major converts the [k*k][C] layout of vip_dwconv2d_nhwc_h2).
+ * vip_dwconv2d_s1_supported_h2 != 0 for the shapes it takes; others return VIP_ERR_UNSUPPORTED (use vip_dwconv2d_nhwc_h2). */
+/* Fused  y = W2 . gelu(W1 . LN(x) + b1) + b2 (+ residual)  on the packed storage (mlp_h2.hip; C = 64 / 96 / 128, hidden % 32 == 0,
+ * M >= 8192 - vip_mlp_fused_supported_h2): the strict form of vip_mlp_fused_f16, same call sites.  x, residual, y packed rows (ldx, ldy,
+ * ldr in logical elements), w1 [hidden][ldw1 halfs] and w2 [C][ldw2 halfs] packed and pre-scaled as for vip_conv2d_nhwc_h2 (b = bias *
+ * scale, out_scale = 1 / scale); ln_gamma / ln_beta NULL: no LayerNorm. */
+int vip_mlp_fused_supported_h2(int M, int C, int hidden, int act);
+int vip_mlp_fused_h2(const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w1, const float* b1, float out_scale1,
+                     const void* w2, const float* b2, float out_scale2, const void* residual, void* y, int M, int C, int hidden, int ldx,
+                     int ldw1, int ldw2, int ldy, int ldr, int act, int* status, void* stream);
+int vip_dw_filter_quad_major(const float* w, float* w_quad, int k, int C, void* stream);
+int vip_dwconv2d_s1_supported_h2(int B, int H, int W, int C, int k, int Ho, int Wo);
+int vip_dwconv2d_s1_h2(const void* x, const float* w_quad, const float* bias, void* y, int B, int H, int W, int C, int k, int pt, int pl,
+                       int Ho, int Wo, int act, int* status, void* stream);
 /* vip_se_gate_f16 on the packed storage: gate [B][Cout] packed; w1 / w2 packed rows of W * scale (ldw in halfs), b = bias * scale,
  * s1 / s2 = 1 / scale */
 int vip_se_gate_h2(const void* x, const void* w1, const float* b1, float s1, const void* w2, const float* b2, float s2, void* gate,

@@ -127,6 +127,32 @@ def test_conv2d_strict_channel_slices_and_gate(mode, report):
     check(report, "conv2d gate", got, R.conv2d(x2 * gate[:, None, None, :], w, b))
 
 
+@pytest.mark.parametrize("C,hidden,M,ln,res", [(96, 384, 9216 + 37, True, True), (64, 256, 8192, True, True), (128, 384, 8192 + 255, True, True),
+                                               (96, 384, 8200, False, False), (128, 512, 8192 + 1, True, False), (64, 192, 12000, False, True)])
+def test_mlp_fused_h2(C, hidden, M, ln, res, report):
+    """the one-launch MLP of the packed storage (csrc/mlp_h2.hip): ragged last tile, with / without LayerNorm and residual, and the same
+    arithmetic as the three-launch form (VIP_MLP_H2_FUSED=0) to fp32 round-off"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(C + hidden)
+    x = torch.randn(M, C, generator=g) * 1.5
+    k1, b1 = torch.randn(C, hidden, generator=g) / math.sqrt(C), torch.randn(hidden, generator=g) * 0.1
+    k2, b2 = torch.randn(hidden, C, generator=g) / math.sqrt(hidden), torch.randn(C, generator=g) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    with ops.precision("strict"):
+        fc1, fc2 = ops.make_dense_weight(k1, b1), ops.make_dense_weight(k2, b2)
+    assert _ops()._abi.lib().vip_mlp_fused_supported_h2(M, C, hidden, 3)
+    xa = A(x, "strict")
+    got = ops.mlp(xa, fc1, fc2, act="gelu", residual=xa if res else None, ln=(dev(gam), dev(bet), 1e-5) if ln else None)
+    h = R.layernorm(x, gam, bet, 1e-5) if ln else x
+    ref = R.dense(R.act(R.dense(h, k1, b1), "gelu"), k2, b2) + (x if res else 0)
+    check(report, f"mlp fused C{C} hidden{hidden} M{M}", got, ref)
+    with ops.unfused():
+        three = ops.mlp(xa, fc1, fc2, act="gelu", residual=xa if res else None, ln=(dev(gam), dev(bet), 1e-5) if ln else None)
+    d = (ops.unpack_h2(got) - ops.unpack_h2(three)).abs().max().item()
+    report(f"[strict-ops] mlp fused vs three launches C{C}: max_abs_diff={d:.3e}")
+    assert d <= 2e-5 * (ref.abs().max().item() + 1e-6)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_dense_mlp_se_strict(mode, report):
     ops = _ops()
@@ -166,6 +192,53 @@ def test_dwconv_strict(k, s, pad, act, mode, report):
     b = torch.randn(40, generator=g) * 0.1
     got = ops.dwconv2d(A(x, mode), ops.make_dw_weight(w), dev(b), k, s, pad, act=act)
     check(report, f"dwconv k{k} s{s}", got, R.act(R.dwconv2d(x, w, b, s, pad), act))
+
+
+# the LDS-staged stride-1 kernel (csrc/dwconv_lds_h2.hip): its lane packings (several images per wave on 7 x 7 / 14 x 14 maps, several
+# regions per image on large ones), partial 16-channel blocks (C = 24, 40, 72), asymmetric padding, maps smaller than the filter
+DW_LDS_CASES = [
+    # B, H, W, C, k, pad(t,b,l,r), act
+    (11, 7, 7, 48, 3, (1, 1, 1, 1), "silu"),
+    (9, 7, 7, 40, 5, (2, 2, 2, 2), "silu"),
+    (3, 14, 14, 72, 5, (2, 2, 2, 2), "silu"),
+    (3, 13, 13, 32, 3, (1, 1, 1, 1), "gelu"),
+    (2, 24, 24, 96, 7, (3, 3, 3, 3), None),
+    (2, 12, 12, 64, 7, (3, 3, 3, 3), None),
+    (1, 99, 99, 24, 7, (3, 3, 3, 3), None),
+    (1, 49, 49, 16, 7, (3, 3, 3, 3), "relu"),
+    (2, 56, 56, 24, 3, (1, 1, 1, 1), "silu"),
+    (1, 112, 112, 8, 3, (1, 1, 1, 1), "silu"),
+    (2, 28, 28, 16, 5, (2, 2, 2, 2), "silu"),
+    (2, 5, 4, 16, 7, (3, 3, 3, 3), None),
+    (2, 17, 19, 16, 3, (0, 0, 0, 0), None),          # VALID: Ho = H - 2
+    (2, 16, 16, 16, 5, (1, 2, 2, 1), "gelu"),
+]
+
+
+@pytest.mark.parametrize("B,H,W,C,k,pad,act", DW_LDS_CASES)
+def test_dwconv_lds_h2(B, H, W, C, k, pad, act, report):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + k)
+    x = torch.randn(B, H, W, C, generator=g)
+    w = torch.randn(k, k, C, 1, generator=g) / k
+    b = torch.randn(C, generator=g) * 0.1
+    got = ops.dwconv2d(A(x, "strict"), ops.make_dw_weight(w), dev(b), k, 1, pad, act=act)
+    check(report, f"dwconv(lds) {B}x{H}x{W}x{C} k{k}", got, R.act(R.dwconv2d(x, w, b, 1, pad), act))
+
+
+def test_dwconv_lds_h2_identity_is_exact():
+    """a centre-tap-only filter returns the input VALUES exactly (the sign of a zero lo term may differ) - small magnitudes included, whose
+    lo terms are fp16 subnormals (the kernel joins hi + lo with v_fma_mix_f32; a flushed subnormal would show here and nowhere in the
+    tolerance tests)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 14, 14, 32, generator=g) * torch.logspace(-6, 1, 32)
+    xp = ops.pack_h2(dev(x))
+    for k in (3, 5, 7):
+        w = torch.zeros(k, k, 32, 1)
+        w[k // 2, k // 2] = 1.0
+        got = ops.dwconv2d(xp, ops.make_dw_weight(w), None, k, 1, (k // 2,) * 4, act=None)
+        assert torch.equal(ops.unpack_h2(got).cpu(), ops.unpack_h2(xp).cpu()), k
 
 
 @pytest.mark.parametrize("mode", MODES)

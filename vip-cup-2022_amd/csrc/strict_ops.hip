@@ -822,7 +822,8 @@ extern "C" int vip_layernorm_h2(const void* x, const float* gamma, const float* 
 }
 extern "C" int vip_dwconv2d_nhwc_h2(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k, int stride,
                                     int pt, int pl, int Ho, int Wo, int act, int* status, void* stream) {
-    // stride 1: the register-tiled kernel of dwconv.hip (the fp16 path's scheme; VIP_DW_H2_TILE=0: the plain kernel below)
+    // stride 1: the register-tiled kernel of dwconv.hip (the fp16 path's scheme; VIP_DW_H2_TILE=0: the plain kernel below).  The LDS-staged
+    // kernel takes a quad-major filter and has its own entry point, vip_dwconv2d_s1_h2 (dwconv_lds_h2.hip)
     static const bool tiled = !(getenv("VIP_DW_H2_TILE") && atoi(getenv("VIP_DW_H2_TILE")) == 0);
     if (tiled && stride == 1 && x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && Ho > 0 && Wo > 0 && pt >= 0 && pl >= 0 &&
         (unsigned)act <= 4u && (long)(Ho - 1) - pt < H && (long)(Wo - 1) - pl < W) {

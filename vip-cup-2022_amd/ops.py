@@ -674,11 +674,39 @@ def dense(x: torch.Tensor, cw: ConvWeight, act=None, act_post=None, residual: Op
     return out
 
 
+_MLP_H2_FUSED = os.environ.get("VIP_MLP_H2_FUSED", "1") != "0"
+
+
 def mlp(x: torch.Tensor, fc1: ConvWeight, fc2: ConvWeight, act="gelu", residual: Optional[torch.Tensor] = None, ln=None):
     """``fc2(act(fc1(LN(x)))) (+ residual)`` over the last axis; ``ln = (gamma, beta, eps)`` or None.  One fused launch
     (LayerNorm in the prologue, hidden tensor in registers) when the C ABI supports the shape, otherwise LayerNorm +
     two Dense launches - same arithmetic either way."""
-    if _kind(x, "mlp.x") != "f16":        # STRICT: LayerNorm, Dense + activation, Dense (+ residual) as three launches
+    kind = _kind(x, "mlp.x")
+    if kind != "f16":
+        C_ = x.shape[-1]
+        M = x.numel() // C_
+        if (kind == "h2" and _MLP_H2_FUSED and not _UNFUSED and fc1.kind == fc2.kind == "h2" and fc2.cout == C_ and fc1.cin == C_
+                and fc2.cin == fc1.cout and fc1.groups == fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1 and x.is_contiguous()
+                and 4 * x.numel() < _H2_SPAN_MAX and _abi.lib().vip_mlp_fused_supported_h2(M, C_, fc1.cout, _act(act))):
+            # one launch (vip_mlp_fused_h2): LayerNorm in the prologue, the hidden tensor in registers
+            out = torch.empty_like(x)
+            if residual is not None:
+                _chkp(residual, "mlp.residual")
+                assert residual.shape == out.shape and residual.is_contiguous()
+            g, b, eps = (ln[0], ln[1], float(ln[2])) if ln is not None else (None, None, 0.0)
+            tok = None
+            if _PROF is not None:
+                tok = _PROF.start("h2:mlp_h2_kernel", 4.0 * M * C_ * fc1.cout,
+                                  4.0 * M * C_ * (3 if residual is not None else 2) + 2.0 * (fc1.w.numel() + fc2.w.numel()),
+                                  f"M={M} C={C_} hidden={fc1.cout}")
+            st = _abi.lib().vip_mlp_fused_h2(_p(x), _p(g), _p(b), eps, _p(fc1.w), _p(fc1.bias), 1.0 / fc1.h2_scale, _p(fc2.w), _p(fc2.bias),
+                                             1.0 / fc2.h2_scale, _p(residual), _p(out), M, C_, fc1.cout, C_, fc1.ldw, fc2.ldw, C_,
+                                             C_ if residual is not None else 0, _act(act), _p(h2_status()), _stream())
+            if tok is not None:
+                _PROF.stop(tok)
+            _abi.check(st, "vip_mlp_fused_h2")
+            return out
+        # otherwise LayerNorm, Dense + activation, Dense (+ residual) as three launches
         if ln is not None:
             x = layernorm(x, ln[0], ln[1], float(ln[2]))
         return dense(dense(x, fc1, act=act), fc2, residual=residual)
@@ -771,6 +799,22 @@ def dense_split(x: torch.Tensor, cw: ConvWeight, act=None) -> torch.Tensor:
     return out
 
 
+_DW_H2_LDS = int(os.environ.get("VIP_DW_H2_LDS", "3"))      # smallest k the LDS-staged strict kernel takes (0: never)
+_DW_QUAD = {}      # filter storage -> (filter, its quad-major copy); the filter is kept alive so that the address cannot be reused
+
+
+def _dw_quad_major(w_khwc: torch.Tensor, k: int) -> torch.Tensor:
+    """``[k,k,C]`` fp32 -> ``[C/4, k*k, 4]`` (vip_dw_filter_quad_major), built once per filter tensor"""
+    key = (w_khwc.data_ptr(), w_khwc._version, tuple(w_khwc.shape))
+    hit = _DW_QUAD.get(key)
+    if hit is None:
+        wq = torch.empty_like(w_khwc)
+        st = _abi.lib().vip_dw_filter_quad_major(_p(w_khwc), _p(wq), k, w_khwc.shape[-1], _stream())
+        _abi.check(st, "vip_dw_filter_quad_major")
+        hit = _DW_QUAD[key] = (w_khwc, wq)
+    return hit[1]
+
+
 def dwconv2d(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stride=1, pad=(0, 0, 0, 0), act=None):
     """Depthwise conv; ``w_khwc`` fp32 ``[k,k,C]``, bias fp32 ``[C]``."""
     kind = _kind(x, "dwconv2d.x")
@@ -782,6 +826,13 @@ def dwconv2d(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, stri
     Wo = (W + pl + pr - k) // stride + 1
     out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
     if kind != "f16":
+        if (kind == "h2" and _DW_H2_LDS and stride == 1 and k >= _DW_H2_LDS
+                and _abi.lib().vip_dwconv2d_s1_supported_h2(B, H, W, Cc, k, Ho, Wo)):
+            # the LDS-staged kernel (dwconv_lds_h2.hip) on the quad-major copy of the filter
+            st = _abi.lib().vip_dwconv2d_s1_h2(_p(x), _p(_dw_quad_major(w_khwc, k)), _p(bias), _p(out), B, H, W, Cc, k, pt, pl, Ho, Wo, _act(act),
+                                               _p(h2_status()), _stream())
+            _abi.check(st, "vip_dwconv2d_s1_h2")
+            return out
         _strict_call("dwconv2d_nhwc", kind, _p(x), _p(w_khwc), _p(bias), _p(out), B, H, W, Cc, k, stride, pt, pl, Ho, Wo, _act(act))
         return out
     st = _abi.lib().vip_dwconv2d_nhwc_f16(_p(x), _p(w_khwc), _p(bias), _p(out), B, H, W, Cc, k, stride, pt, pl,
