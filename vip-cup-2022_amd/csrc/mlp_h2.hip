@@ -34,7 +34,7 @@ struct MlpH2Args {
     int ldx, ldy, ldr;   // logical elements per row
     int ldw1, ldw2;      // halfs per packed weight row
     int s1, s2;          // LDS row strides (bytes) of the W1 slice [32 rows] and the W2 slice [C rows]
-    int n_tiles;         // tiles of 256 tokens
+    int n_tiles;         // tiles of 32 tokens per wave
     int* status;
 };
 
@@ -88,10 +88,10 @@ __device__ __forceinline__ void ln_fragments_h2(U4H8 (&xh)[CK], U4H8 (&xl)[CK], 
     }
 }
 
-template <int CK>
-__global__ __launch_bounds__(512, 2) void mlp_h2_kernel(MlpH2Args a) {
-    constexpr int C = 32 * CK, PT = 2, NCT = C / 16, NTHR = 512;
-    constexpr int W_IT = C / 32;                    // 16-byte weight chunks staged per thread per slice (16 C / 512)
+template <int CK, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void mlp_h2_kernel(MlpH2Args a) {
+    constexpr int C = 32 * CK, PT = 2, NCT = C / 16, NTHR = 64 * NW;
+    constexpr int W_IT = 16 * C / NTHR;             // 16-byte weight chunks staged per thread per slice
     constexpr unsigned OOB = 0xFFFFFFE0u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int stage_bytes = 32 * a.s1 + C * a.s2;   // W1 slice [32][s1] then W2 slice [C][s2]
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void mlp_h2_kernel(MlpH2Args a) {
     const __amdgpu_buffer_rsrc_t rb1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b1, 0, a.b1 ? (unsigned)(a.Hd * 4) : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.b2, 0, a.b2 ? (unsigned)(C * 4) : 0u, 0x00020000);
 
-    // staging plan of this thread: chunk idx = tid + 512 i; the first 8C chunks are the W1 slice (32 rows x C/4 chunks), the rest the W2
+    // staging plan of this thread: chunk idx = tid + NTHR i; the first 8C chunks are the W1 slice (32 rows x C/4 chunks), the rest the W2
     // slice (C rows x 8 chunks).  Plain pointers: one load instruction per chunk whichever matrix it comes from.
     const char* w_ptr[W_IT];   // source of slice 0
     unsigned w_step[W_IT];     // bytes between consecutive slices
@@ -125,14 +125,15 @@ __global__ __launch_bounds__(512, 2) void mlp_h2_kernel(MlpH2Args a) {
             w_dst[i] = 32 * a.s1 + row * a.s2 + h2_pos(c) * 16;
         }
     }
-    uint4 wst[W_IT];
+    typedef unsigned wvec4 __attribute__((ext_vector_type(4)));      // a native vector: hip's uint4 struct made this array a stack object
+    wvec4 wst[W_IT];
     auto load_w = [&](int q) {
 #pragma unroll
-        for (int i = 0; i < W_IT; ++i) wst[i] = *reinterpret_cast<const uint4*>(w_ptr[i] + (size_t)q * w_step[i]);
+        for (int i = 0; i < W_IT; ++i) wst[i] = *reinterpret_cast<const wvec4*>(w_ptr[i] + (size_t)q * w_step[i]);
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < W_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * stage_bytes + w_dst[i]) = wst[i];
+        for (int i = 0; i < W_IT; ++i) *reinterpret_cast<wvec4*>(__builtin_assume_aligned(smem + buf * stage_bytes + w_dst[i], 16)) = wst[i];
     };
 
     const int nq = a.Hd >> 5;
@@ -225,10 +226,8 @@ __global__ __launch_bounds__(512, 2) void mlp_h2_kernel(MlpH2Args a) {
                         hh[p].e[t * 4 + j] = h.x;
                         hh[p].e[t * 4 + j + 1] = h.y;
                         hl[p].e[t * 4 + j] = l.x;
-                        hl[p].e[t * 4 + j + 1] = l.y;
-                        ov_sum += v;
-                        ov_max = fmaxf(ov_max, fmaxf(fabsf(v.x), fabsf(v.y)));
-                    }
+                        hl[p].e[t * 4 + j + 1] = l.y;      // (a hidden value beyond the fp16 range becomes Inf here and NaN / Inf in y: the
+                    }                                      //  range check of the outputs below reports it)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 U4H8 wh, wl;
@@ -295,13 +294,13 @@ int mlp_h2_stride(int chunks) {
     return chunks * 16;
 }
 
-template <int CK>
+template <int CK, int NW>
 int launch_mlp_h2(MlpH2Args a, hipStream_t s) {
     constexpr int C = 32 * CK;
     a.s1 = mlp_h2_stride(C / 4);
     a.s2 = mlp_h2_stride(8);
     const size_t smem = 2 * ((size_t)32 * a.s1 + (size_t)C * a.s2);
-    a.n_tiles = (a.M + 255) / 256;
+    a.n_tiles = (a.M + 32 * NW - 1) / (32 * NW);
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -311,13 +310,17 @@ int launch_mlp_h2(MlpH2Args a, hipStream_t s) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_h2_kernel<CK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_h2_kernel<CK, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    // C = 64: 124 VGPRs and 39 KB of LDS - two workgroups per CU
-    const int cap = n_cu * (CK == 2 ? 2 : 1);
+    // workgroups per CU: what the LDS images allow (two waves per SIMD either way).  Two independent 4-wave workgroups drift apart in
+    // phase - one in its MFMA runs while the other evaluates GELU - where one 8-wave workgroup is locked to a barrier per slice
+    int per_cu = (int)((160 * 1024) / (smem + 1024));
+    if (per_cu > 8 / NW * 2) per_cu = 8 / NW * 2;
+    if (per_cu < 1) per_cu = 1;
+    const int cap = n_cu * per_cu;
     const int grid = a.n_tiles < cap ? a.n_tiles : cap;
-    hipLaunchKernelGGL((mlp_h2_kernel<CK>), dim3(grid), dim3(512), smem, s, a);
+    hipLaunchKernelGGL((mlp_h2_kernel<CK, NW>), dim3(grid), dim3(64 * NW), smem, s, a);
     return vip_launch_status("vip_mlp_fused_h2");
 }
 
@@ -352,7 +355,17 @@ extern "C" int vip_mlp_fused_h2(const void* x, const float* ln_gamma, const floa
     a.M = M; a.Hd = hidden; a.ldx = ldx; a.ldy = ldy; a.ldr = ldr; a.ldw1 = ldw1; a.ldw2 = ldw2;
     a.s1 = a.s2 = a.n_tiles = 0;
     a.status = status;
-    if (C == 64) return launch_mlp_h2<2>(a, (hipStream_t)stream);
-    if (C == 96) return launch_mlp_h2<3>(a, (hipStream_t)stream);
-    return launch_mlp_h2<4>(a, (hipStream_t)stream);
+    // waves per workgroup, measured (profiles/r04_mlp_h2_ab.log): C = 64 / 128 prefer two 4-wave workgroups per CU (307 vs 346 us,
+    // 239 vs 273 us), C = 96 one 8-wave workgroup (1 843 vs 1 985 us: half the weight traffic out of L2).  VIP_MLP_H2_WAVES overrides.
+    static const int nw_env = getenv("VIP_MLP_H2_WAVES") ? atoi(getenv("VIP_MLP_H2_WAVES")) : 0;
+    const int nw = nw_env ? nw_env : (C == 96 ? 8 : 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (nw == 8) {
+        if (C == 64) return launch_mlp_h2<2, 8>(a, s);
+        if (C == 96) return launch_mlp_h2<3, 8>(a, s);
+        return launch_mlp_h2<4, 8>(a, s);
+    }
+    if (C == 64) return launch_mlp_h2<2, 4>(a, s);
+    if (C == 96) return launch_mlp_h2<3, 4>(a, s);
+    return launch_mlp_h2<4, 4>(a, s);
 }
