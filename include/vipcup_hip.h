@@ -402,6 +402,10 @@ int vip_unpack_h2(const void* x, float* y, long n, void* stream);
 int vip_conv2d_nhwc_h2(const void* x, const void* w, const float* bias, const void* residual, void* y, const vip_conv_desc* d,
                        float out_scale, int* status, void* stream);
 int vip_conv2d_kernel_name_h2(const vip_conv_desc* d, int has_residual, char* name, size_t cap);
+/* vip_conv2d_gated_nhwc_f16 on the packed storage: gate packed [B][Cin] (vip_se_gate_h2), multiplied into the activation operand in fp32
+ * and split again in registers; 1x1 stride-1 ungrouped, (activation) or (residual [+ReLU]) epilogue, cin_off = 0, ldx = Cin. */
+int vip_conv2d_gated_nhwc_h2(const void* x, const void* gate, const void* w, const float* bias, const void* residual, void* y,
+                             const vip_conv_desc* d, float out_scale, int* status, void* stream);
 /* every other operator, arguments as the _s32 form (strict_ops.hip: one kernel template, two storages); fp32 parameters (LayerNorm
  * gamma / beta, depthwise filters, head matrices, relative-position table) and fp32 head outputs as there */
 int vip_dwconv2d_nhwc_h2(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int C, int k, int stride,

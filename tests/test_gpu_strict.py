@@ -127,6 +127,31 @@ def test_conv2d_strict_channel_slices_and_gate(mode, report):
     check(report, "conv2d gate", got, R.conv2d(x2 * gate[:, None, None, :], w, b))
 
 
+@pytest.mark.parametrize("B,HW,Cin,Cout,act,res", [(4, 14, 96, 40, None, False), (3, 14, 96, 160, None, True), (2, 7, 24, 72, "silu", False),
+                                                   (5, 13, 416, 112, None, False), (70, 28, 48, 24, None, True), (2, 7, 1248, 208, None, True)])
+def test_conv2d_gated_h2(B, HW, Cin, Cout, act, res, report):
+    """the squeeze-excite gate inside the GEMM's activation operand (vip_conv2d_gated_nhwc_h2): one or several k chunks, a partial chunk,
+    64- and 128-channel tiles, 16- and 64-pixel wave tiles, and the same values as the separate multiply pass"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = torch.randn(B, HW, HW, Cin, generator=g)
+    gate = torch.rand(B, Cin, generator=g) * 1.2
+    w = torch.randn(1, 1, Cin, Cout, generator=g) / math.sqrt(Cin)
+    b = torch.randn(Cout, generator=g) * 0.1
+    r = torch.randn(B, HW, HW, Cout, generator=g) if res else None
+    with ops.precision("strict"):
+        cw = ops.make_conv_weight(w, b)
+    xa, ga, ra = A(x, "strict"), A(gate, "strict"), (A(r, "strict") if res else None)
+    got = ops.conv2d(xa, cw, act=act, gate=ga, residual=ra)
+    ref = R.act(R.conv2d(x * gate[:, None, None, :], w, b), act) + (r if res else 0)
+    check(report, f"conv2d gated {B}x{HW}x{HW}x{Cin}->{Cout}", got, ref)
+    with ops.unfused():
+        two = ops.conv2d(xa, cw, act=act, gate=ga, residual=ra)
+    d = (ops.unpack_h2(got) - ops.unpack_h2(two)).abs().max().item()
+    report(f"[strict-ops] gated conv vs multiply + conv: max_abs_diff={d:.3e}")
+    assert d <= 2e-5 * (ref.abs().max().item() + 1e-6)
+
+
 @pytest.mark.parametrize("C,hidden,M,ln,res", [(96, 384, 9216 + 37, True, True), (64, 256, 8192, True, True), (128, 384, 8192 + 255, True, True),
                                                (96, 384, 8200, False, False), (128, 512, 8192 + 1, True, False), (64, 192, 12000, False, True)])
 def test_mlp_fused_h2(C, hidden, M, ln, res, report):

@@ -103,6 +103,7 @@ SIGNATURES = {
     "vip_pack_h2": (_i, [_vp, _vp, C.c_long, _vp, _vp]),
     "vip_unpack_h2": (_i, [_vp, _vp, C.c_long, _vp]),
     "vip_conv2d_nhwc_h2": (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _f, _vp, _vp]),
+    "vip_conv2d_gated_nhwc_h2": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ConvDesc), _f, _vp, _vp]),
     "vip_conv2d_kernel_name_h2": (_i, [C.POINTER(ConvDesc), _i, C.c_char_p, _sz]),
     "vip_dwconv2d_nhwc_h2": (_i, [_vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _vp]),
     "vip_mlp_fused_supported_h2": (_i, [_i] * 4),

@@ -727,12 +727,14 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
     // squeeze-excite gate folded into the activation operand: x[m, k] * (hi + lo)[image(m), k] as fma(x, hi, x * lo) in
     // packed fp16 - the product is rounded once, per element; the gate itself carries ~22 bits (see se_gate.hip)
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.gate, 0, GATED ? (unsigned)min((long)0xFFFFFFF0L, 4L * ((a.M + a.gate_hw - 1) / a.gate_hw) * a.K) : 0u, 0x00020000);
+        (void*)a.gate, 0, GATED ? (unsigned)min((long)0xFFFFFFF0L, (H2 ? 2L : 4L) * ((a.M + a.gate_hw - 1) / a.gate_hw) * a.K) : 0u, 0x00020000);
+    // H2: the gate is a packed [B][Cin] tensor (a.K = 2 Cin halfs per image); the lane's 8 channels are the 32-byte pair lq of the chunk
     unsigned g_off[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int m = m0 + p * 16 + l15;
-        g_off[p] = (GATED && m < a.M) ? (unsigned)(((m / a.gate_hw) * 2 * a.K + lq * 8) * 2) : 0xFFFF0000u;
+        g_off[p] = (GATED && m < a.M) ? (H2 ? (unsigned)((m / a.gate_hw) * a.K * 2 + lq * 32) : (unsigned)(((m / a.gate_hw) * 2 * a.K + lq * 8) * 2))
+                                      : 0xFFFF0000u;
     }
     const int nk = (a.K + 63) >> 6;
 
@@ -761,7 +763,14 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
     // re-requested at once for the following k-step, landing under the MFMAs in between.  The buffer is [B][2][K]
     // halfs, L1/L2-resident.
     auto load_g = [&](int kc, int ks) {
-        if constexpr (GATED) {
+        if constexpr (GATED && H2) {         // both planes of the chunk's gate values, once per chunk (ks unused)
+            const bool ok = kc * 64 + lq * 16 < a.K;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                gq[0][p].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? g_off[p] + kc * 128 : OOB, 0, 0));
+                gq[1][p].u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rg, ok ? g_off[p] + kc * 128 + 16 : OOB, 0, 0));
+            }
+        } else if constexpr (GATED) {
             const bool ok = kc * 64 + ks * 32 + lq * 8 < a.K;
 #pragma unroll
             for (int p = 0; p < PT; ++p) {
@@ -773,7 +782,17 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
         }
     };
     auto gate_x = [&](int ks) {
-        if constexpr (GATED) {
+        if constexpr (GATED && H2) {         // (x_hi + x_lo) * (g_hi + g_lo) in fp32, split again: both planes of the chunk at once
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                float xv[8], gv[8];
+                h2_join8(xf[0][p], xf[1][p], xv);
+                h2_join8(gq[0][p], gq[1][p], gv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] *= gv[j];
+                h2_split8(xv, xf[0][p], xf[1][p]);
+            }
+        } else if constexpr (GATED) {
 #pragma unroll
             for (int p = 0; p < PT; ++p)                                              // 4 x (v_pk_mul_f16 + v_pk_fma_f16)
                 xf[ks][p].h = __builtin_elementwise_fma(xf[ks][p].h, gq[0][p].h, xf[ks][p].h * gq[1][p].h);
@@ -849,7 +868,12 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
         const int buf = kc & 1;
         load_w(kc + 1);
         __builtin_amdgcn_sched_barrier(0);   // pin the issue points: the scheduler otherwise sinks every load below
-        if constexpr (GATED) {               // the MFMAs, right in front of its wait
+        if constexpr (GATED && H2) {         // the MFMAs, right in front of its wait
+            gate_x(0);                       // both planes of chunk kc
+            __builtin_amdgcn_sched_barrier(0);
+            load_g(kc + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (GATED) {
             gate_x(0);
             __builtin_amdgcn_sched_barrier(0);
             load_g(kc, 1);
@@ -859,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
         __builtin_amdgcn_sched_barrier(0);
         load_x(kc + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (GATED) {
+        if constexpr (GATED && !H2) {
             gate_x(1);
             __builtin_amdgcn_sched_barrier(0);
             load_g(kc + 1, 0);
@@ -1550,8 +1574,8 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
     constexpr int IN = H2 ? 2 : 1;       // halfs per input element (H2: an (hi, lo) pair)
     VIP_REQUIRE(d->ldx >= d->cin_off + d->Cin && d->ldy >= d->cout_off + d->Cout && d->ldw >= IN * d->kh * d->kw * cin_g,
                 VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_f16: leading dimension smaller than the channel extent");
-    VIP_REQUIRE(!H2 || (d->ldw % 16 == 0 && !gate && !w_lo && !y_lo_off && !x_split), VIP_ERR_BAD_ARG,
-                "vip_conv2d_nhwc_h2: ldw must be a multiple of 16 halfs; no gate / split variants");
+    VIP_REQUIRE(!H2 || (d->ldw % 16 == 0 && !w_lo && !y_lo_off && !x_split), VIP_ERR_BAD_ARG,
+                "vip_conv2d_nhwc_h2: ldw must be a multiple of 16 halfs; no split variants");
     VIP_REQUIRE((unsigned)d->act_pre <= 4u && (unsigned)d->act_post <= 4u, VIP_ERR_BAD_ARG,
                 "vip_conv2d_nhwc_f16: unknown activation code");
     // the caller's Ho/Wo must not read past what padding+kernel imply on the top/left; bottom/right
@@ -1666,6 +1690,18 @@ extern "C" int vip_conv2d_nhwc_h2(const void* x, const void* w, const float* bia
                                   float out_scale, int* status, void* stream) {
     VIP_REQUIRE(out_scale > 0.f, VIP_ERR_BAD_ARG, "vip_conv2d_nhwc_h2: out_scale must be positive");
     return conv2d_impl(x, nullptr, 0, w, bias, residual, y, d, stream, nullptr, false, out_scale, status);
+}
+
+/* The same with a squeeze-excite gate folded into the activation operand: gate packed [B][Cin]; the product (x_hi + x_lo)(g_hi + g_lo) is
+ * formed in fp32 per element and split again in registers (pwk_direct_kernel) - only 1x1 stride-1 ungrouped convolutions with an
+ * (activation) or (residual [+ReLU]) epilogue, cin_off = 0, ldx = Cin; anything else returns VIP_ERR_UNSUPPORTED. */
+extern "C" int vip_conv2d_gated_nhwc_h2(const void* x, const void* gate, const void* w, const float* bias, const void* residual, void* y,
+                                        const vip_conv_desc* d, float out_scale, int* status, void* stream) {
+    VIP_REQUIRE(gate, VIP_ERR_BAD_ARG, "vip_conv2d_gated_nhwc_h2: null gate");
+    VIP_REQUIRE(out_scale > 0.f, VIP_ERR_BAD_ARG, "vip_conv2d_gated_nhwc_h2: out_scale must be positive");
+    VIP_REQUIRE(d && d->cin_off == 0 && d->ldx == d->Cin, VIP_ERR_UNSUPPORTED,
+                "vip_conv2d_gated_nhwc_h2: the gate indexes the whole input channel axis (cin_off = 0, ldx = Cin)");
+    return conv2d_impl(x, gate, 0, w, bias, residual, y, d, stream, nullptr, false, out_scale, status);
 }
 
 extern "C" int vip_conv2d_kernel_name_h2(const vip_conv_desc* d, int has_residual, char* name, size_t cap) {

@@ -550,15 +550,26 @@ def conv_kernel_name_h2(d: "_abi.ConvDesc", has_residual: bool) -> Optional[str]
 _H2_SPAN_MAX = 0xFFFFFFE0       # the C kernels address every tensor through 32-bit buffer offsets
 
 
+_H2_GATED = os.environ.get("VIP_H2_GATED", "1") != "0"
+
+
 def _conv2d_h2(x, cw: ConvWeight, stride, pad, act, act_post, residual, out, cin_off, cout_off, gate):
     """packed-STRICT conv2d: packed x / residual / out, vip_conv2d_nhwc_h2; a packed gate [B, Cin] is multiplied in first.  Tensors
     beyond the 4 GiB the kernels can address are processed in batch slices (images are independent)."""
-    if gate is not None:
-        assert gate.shape == (x.shape[0], cw.cin) and x.shape[3] == cw.cin and cin_off == 0, (gate.shape, x.shape, cw.cin)
-        x = scale_add_act(x, gate, None, None)
-    B, H, W, ldx = x.shape
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     pt, pb, pl, pr = pad
+    if gate is not None:
+        assert gate.shape == (x.shape[0], cw.cin) and x.shape[3] == cw.cin and cin_off == 0, (gate.shape, x.shape, cw.cin)
+        _chkp(gate, "conv2d.gate")
+        # in the GEMM's activation operand (vip_conv2d_gated_nhwc_h2) where the C ABI carries it: 1x1 stride-1 ungrouped, no padding,
+        # (activation) or (residual [+ReLU]) epilogue; otherwise a separate multiply pass first
+        fold = (_H2_GATED and not _UNFUSED and cw.kh == cw.kw == 1 and (sh, sw) == (1, 1) and cw.groups == 1 and pad == (0, 0, 0, 0)
+                and 4 * x.numel() < 0xFFFF0000 - 4 * cw.cin
+                and ((residual is None and act_post is None) or (residual is not None and act is None and act_post in (None, "relu"))))
+        if not fold:
+            x = scale_add_act(x, gate, None, None)
+            gate = None
+    B, H, W, ldx = x.shape
     Ho = (H + pt + pb - cw.kh) // sh + 1
     Wo = (W + pl + pr - cw.kw) // sw + 1
     if out is None:
@@ -581,14 +592,19 @@ def _conv2d_h2(x, cw: ConvWeight, stride, pad, act, act_post, residual, out, cin
         if _PROF is not None:
             M = (b1 - b0) * Ho * Wo
             kk = cw.kh * cw.kw * cw.alg_cin_g
-            tok = _PROF.start("h2:" + (conv_kernel_name_h2(d, residual is not None) or "unsupported"), 2.0 * M * cw.cout * kk,
+            tok = _PROF.start("h2:" + ("pwk_direct_kernel" if gate is not None else conv_kernel_name_h2(d, residual is not None) or "unsupported"),
+                              2.0 * M * cw.cout * kk,
                               4.0 * ((b1 - b0) * H * W * cw.cin + M * cw.cout * (2 if residual is not None else 1)) + 2.0 * cw.w.numel(),
                               f"M={M} N={cw.cout} K={cw.kh * cw.kw * cw.cin_g} k{cw.kh} s{sh} g{cw.groups}")
-        st = _abi.lib().vip_conv2d_nhwc_h2(_p(xs), _p(cw.w), _p(cw.bias), _p(rs), _p(os_), C.byref(d), 1.0 / cw.h2_scale,
-                                           _p(h2_status()), _stream())
+        if gate is not None:
+            st = _abi.lib().vip_conv2d_gated_nhwc_h2(_p(xs), _p(gate[b0:b1]), _p(cw.w), _p(cw.bias), _p(rs), _p(os_), C.byref(d), 1.0 / cw.h2_scale,
+                                                     _p(h2_status()), _stream())
+        else:
+            st = _abi.lib().vip_conv2d_nhwc_h2(_p(xs), _p(cw.w), _p(cw.bias), _p(rs), _p(os_), C.byref(d), 1.0 / cw.h2_scale,
+                                               _p(h2_status()), _stream())
         if tok is not None:
             _PROF.stop(tok)
-        _abi.check(st, "vip_conv2d_nhwc_h2")
+        _abi.check(st, "vip_conv2d_gated_nhwc_h2" if gate is not None else "vip_conv2d_nhwc_h2")
     return out
 
 
