@@ -282,6 +282,40 @@ def test_dense_gemm8p(M, K, N, mode, report, monkeypatch):
     assert torch.equal(got, got2), "two launches on the same operands must agree bit for bit (no race in the DMA ring)"
 
 
+# the activation-resident short-K / wide-N kernel (pwx_kernel in csrc/conv_igemm.hip: K <= 256, N >= 256, M >= 16384): 2 / 3 / 4 k chunks and a
+# K tail, a half-empty last channel tile, ragged M, every epilogue family; the dispatcher must really pick it, and it must agree bit for bit
+# with the kernel it replaces (VIP_PWX=0 is read once per process, so the comparison is against the fp32 oracle and a repeat launch)
+@pytest.mark.parametrize("mode", ["gelu", "res", "res_relu", "none"])
+@pytest.mark.parametrize("M,K,N", [(16384 + 37, 256, 768), (20000, 192, 320), (16500, 128, 256), (17000, 200, 1024), (16384, 72, 384)])
+def test_dense_pwx(M, K, N, mode, report, monkeypatch):
+    monkeypatch.setenv("VIP_PWX", "1")          # an experiment, off by default; read per call
+    ops = _ops()
+    from vipcup_amd import _abi
+    g = torch.Generator().manual_seed(M + K + N)
+    x = h(torch.randn(M, K, generator=g))
+    w = h(torch.randn(K, N, generator=g) / math.sqrt(K))
+    b = torch.randn(N, generator=g) * 0.1
+    cw = ops.make_dense_weight(w, b)
+    has_res = mode in ("res", "res_relu")
+    d = _abi.ConvDesc(B=M, H=1, W=1, Cin=K, Cout=N, kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Ho=1, Wo=1, groups=1, ldx=K, cin_off=0, ldy=N,
+                      cout_off=0, ldr=N if has_res else 0, res_off=0, ldw=cw.ldw, act_pre=3 if mode == "gelu" else 0,
+                      act_post=1 if mode == "res_relu" else 0)
+    assert ops.conv_kernel_name(d, has_res) == "pwx_kernel"
+    if has_res:
+        res = h(torch.randn(M, N, generator=g))
+        post = "relu" if mode == "res_relu" else None
+        ref = R.act(R.dense(x, w, b) + res, post)
+        run = lambda: ops.dense(dev(x), cw, act_post=post, residual=dev(res))  # noqa: E731
+    else:
+        act = None if mode == "none" else mode
+        ref = R.act(R.dense(x, w, b), act)
+        run = lambda: ops.dense(dev(x), cw, act=act)  # noqa: E731
+    got = run()
+    torch.cuda.synchronize()
+    check(report, f"dense-pwx {mode} {M}x{K}x{N}", got, ref)
+    assert torch.equal(got, run()), "two launches on the same operands must agree bit for bit"
+
+
 # fused MLP (hidden tensor in registers): LDS-resident (C 64/96) and streamed (C 192) weights, M tails, with/without residual, vs two fp32 denses
 @pytest.mark.parametrize("use_ln", [False, True])
 @pytest.mark.parametrize("M,C,hid,use_res", [(8192, 96, 384, True), (20011, 96, 384, False), (9000, 64, 256, True),

@@ -127,6 +127,26 @@ def test_conv2d_strict_channel_slices_and_gate(mode, report):
     check(report, "conv2d gate", got, R.conv2d(x2 * gate[:, None, None, :], w, b))
 
 
+@pytest.mark.parametrize("M,K,N,act,res", [(16384 + 37, 256, 768, "gelu", False), (20000, 192, 320, None, True), (16500, 128, 256, None, False),
+                                           (17000, 200, 1024, "silu", False), (16384, 72, 384, None, True)])
+def test_dense_pwx_h2(M, K, N, act, res, report, monkeypatch):
+    """the activation-resident short-K / wide-N kernel on the packed storage (pwx_kernel: 4 / 6 / 8 half-chunks of K, 32 or 16 pixels per
+    wave), K tails, a half-empty last channel tile, ragged M"""
+    monkeypatch.setenv("VIP_PWX", "1")          # an experiment, off by default (DESIGN section 8); read per call
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w, b = torch.randn(K, N, generator=g) / math.sqrt(K), torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g) if res else None
+    with ops.precision("strict"):
+        cw = ops.make_dense_weight(w, b)
+    d = ops._abi.ConvDesc(B=M, H=1, W=1, Cin=K, Cout=N, kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Ho=1, Wo=1, groups=1, ldx=K, cin_off=0, ldy=N,
+                          cout_off=0, ldr=N if res else 0, res_off=0, ldw=cw.ldw, act_pre=ops._act(act), act_post=0)
+    assert ops.conv_kernel_name_h2(d, res) == "pwx_kernel"
+    got = ops.dense(A(x, "strict"), cw, act=act, residual=A(r, "strict") if res else None)
+    check(report, f"dense pwx {M}x{K}x{N}", got, R.act(R.dense(x, w, b), act) + (r if res else 0))
+
+
 @pytest.mark.parametrize("B,HW,Cin,Cout,act,res", [(4, 14, 96, 40, None, False), (3, 14, 96, 160, None, True), (2, 7, 24, 72, "silu", False),
                                                    (5, 13, 416, 112, None, False), (70, 28, 48, 24, None, True), (2, 7, 1248, 208, None, True)])
 def test_conv2d_gated_h2(B, HW, Cin, Cout, act, res, report):

@@ -920,6 +920,190 @@ __global__ __launch_bounds__(256, 2) void pwk_direct_kernel(ConvArgs a, int mode
 }
 
 
+// ---- pointwise / dense layers with SHORT K and WIDE N: activations resident in registers, weights streamed over all of N ----
+// pwk_direct_kernel gives every 128-channel slice of the output its own workgroup: with K <= 256 that workgroup runs 2-4 k-chunks, so its
+// life is one pipeline fill (the first weight chunk and activation fragments: ~2 us of L2 / HBM latency) and one drain (the epilogue)
+// around ~1 us of MFMAs, and each of the N / 128 workgroups of a pixel tile fetches the same activations again (PMC, round 3: matrix
+// pipe 30 % busy, half of a wave's life in s_waitcnt).  Here a workgroup keeps the activation fragments of ALL of K in registers
+// (KSC 64-half chunks: <= 64 VGPRs at 32 pixels per wave) and walks over every 128-channel tile of N: the weight chunks of
+// (tile, chunk) pairs stream through the same double-buffered LDS image back to back - the prefetch of tile t+1's first chunk is issued
+// under tile t's last MFMAs, so there is one fill per workgroup instead of one per 128 channels - and the activations are read once.
+template <int KSC, int PT>
+__global__ __launch_bounds__(256, 2) void pwx_kernel(ConvArgs a, int mode) {
+    constexpr int NG = 2, NB = 64 * NG, ROWB = 160;
+    constexpr int STAGE = NB * ROWB;
+    constexpr int W_IT = NB / 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    int bid = blockIdx.x;
+    {   // XCD-contiguous pixel tiles (as pwk_direct_kernel)
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = bid * (64 * PT) + wave * (16 * PT);
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (unsigned)min((long)0xFFFFFFF0L, 2L * a.Cout_g * a.ldw), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.x + a.cin_off), 0, (unsigned)min((long)0xFFFFFFF0L, a.x_span_bytes - 2L * a.cin_off), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_res =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (unsigned)a.res_span_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_y = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (unsigned)a.y_span_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_bias =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)(a.bias_elems * 4) : 0u, 0x00020000);
+
+    // weight staging: thread -> (LDS row j = tid/8 + 32 i, 16-byte chunk c = tid%8); row j holds channel n0 + perm(j)
+    const int wc = tid & 7;
+    int w_ch[W_IT], w_lds[W_IT];
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+        const int j = (tid >> 3) + 32 * i;
+        const int t = (j >> 4) & 3, r = j & 15;
+        w_ch[i] = (j & ~63) + (t >> 1) * 32 + (r >> 2) * 8 + (t & 1) * 4 + (r & 3);
+        w_lds[i] = j * ROWB + h2_pos(wc) * 16;
+    }
+    uint4 wst[W_IT];
+    auto load_w = [&](int n0, int kc) {
+        const bool okk = kc * 64 + wc * 8 < a.K;
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) {
+            const int ch = n0 + w_ch[i];
+            wst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   rw, (okk && ch < a.Cout_g) ? (unsigned)((ch * a.ldw + wc * 8) * 2) + kc * 128 : OOB, 0, 0));
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < W_IT; ++i) *reinterpret_cast<uint4*>(smem + buf * STAGE + w_lds[i]) = wst[i];
+    };
+
+    // the activation fragments of the whole K axis (masked beyond K: the weights there are zero in LDS, but 0 * garbage may be NaN)
+    U4H8 xf[2 * KSC][PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int m = m0 + p * 16 + l15;
+        const unsigned xo = m < a.M ? (unsigned)((m * a.ldx + lq * (H2 ? 16 : 8)) * 2) : 0xFFFF0000u;
+#pragma unroll
+        for (int kc = 0; kc < KSC; ++kc)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bool ok = kc * 64 + (H2 ? lq * 16 + ks * 8 : ks * 32 + lq * 8) < a.K;
+                xf[2 * kc + ks][p].u = __builtin_bit_cast(
+                    uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xo + kc * 128 + ks * (H2 ? 16 : 64) : OOB, 0, 0));
+            }
+    }
+
+    f32x4 acc[NG][PT][4];
+    auto init_acc = [&](int n0) {     // bias is the C operand of the first MFMA of every accumulator
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + g * 64 + (nt >> 1) * 32 + lq * 8 + (nt & 1) * 4;
+                const f32x4 bv = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_bias, n < a.Cout_g ? (unsigned)(n * 4) : OOB, 0, 0));
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[g][p][nt] = bv;
+            }
+    };
+    auto compute = [&](int buf, int ks, const U4H8 (&xk)[2][PT]) {
+        const char* ws = smem + buf * STAGE + l15 * ROWB + lq * 16 + ks * 64;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            U4H8 wf[4];
+            if constexpr (H2) {      // ks = 0: x hi against the weights' lo and hi planes; ks = 1: x lo against the hi plane
+                const char* wh = ws - ks * 64;
+                U4H8 wl[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(wh + (g * 64 + nt * 16) * ROWB);
+                if (ks == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) wl[nt].u = *reinterpret_cast<const uint4*>(wh + 64 + (g * 64 + nt * 16) * ROWB);
+                }
+                if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) {
+                        if (ks == 0) acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[nt].h, xk[0][p].h, acc[g][p][nt], 0, 0, 0);
+                        acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xk[ks][p].h, acc[g][p][nt], 0, 0, 0);
+                    }
+                if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+                continue;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[nt].u = *reinterpret_cast<const uint4*>(ws + (g * 64 + nt * 16) * ROWB);
+            if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int p = 0; p < PT; ++p) acc[g][p][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt].h, xk[ks][p].h, acc[g][p][nt], 0, 0, 0);
+            if (VIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
+    const int n_tiles = (a.Cout_g + NB - 1) / NB;
+    load_w(0, 0);
+    store_w(0);
+    __syncthreads();
+    int buf = 0;
+#pragma unroll 1
+    for (int t = 0; t < n_tiles; ++t) {
+        const int n0 = t * NB;
+        init_acc(n0);
+#pragma unroll
+        for (int kc = 0; kc < KSC; ++kc) {
+            // next (tile, chunk) pair; past the last tile every offset is out of range (zeros, no traffic)
+            if (kc + 1 < KSC) load_w(n0, kc + 1);
+            else load_w(n0 + NB, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            U4H8 xk[2][PT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                xk[0][p] = xf[2 * kc][p];
+                xk[1][p] = xf[2 * kc + 1][p];
+            }
+            compute(buf, 0, xk);
+            compute(buf, 1, xk);
+            __builtin_amdgcn_sched_barrier(0);
+            store_w(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        int m_base = m0 + l15, n_lane = n0 + lq * 8;
+        asm volatile("" : "+v"(m_base), "+v"(n_lane));
+        auto epi = [&](auto gtag) {
+            constexpr int G_ = decltype(gtag)::value;
+            const int n_first = n_lane + G_ * 64;
+            switch (mode) {
+                case 1: pw_epilogue<PT, VIP_ACT_RELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 2: pw_epilogue<PT, VIP_ACT_SILU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 3: pw_epilogue<PT, VIP_ACT_GELU, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 4: pw_epilogue<PT, VIP_ACT_SIGMOID, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 5: pw_epilogue<PT, VIP_ACT_NONE, true, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                case 6: pw_epilogue<PT, VIP_ACT_NONE, true, true>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+                default: pw_epilogue<PT, VIP_ACT_NONE, false, false>(a, acc[G_], m_base, n_first, rb_res, rb_y); break;
+            }
+        };
+        epi(std::integral_constant<int, 0>{});
+        epi(std::integral_constant<int, 1>{});
+    }
+}
+
+template <int KSC, int PT>
+int launch_pwx(const ConvArgs& a0, int mode, hipStream_t s) {
+    ConvArgs a = a0;
+    a.m_blocks = (a.M + 64 * PT - 1) / (64 * PT);
+    a.n_blocks = 1;
+    hipLaunchKernelGGL((pwx_kernel<KSC, PT>), dim3((unsigned)a.m_blocks), dim3(256), 0, s, a, mode);
+    return vip_launch_status("vip_conv2d_nhwc_f16(pwx)");
+}
+
 #if VIP_BUILD_EXPERIMENTS
 // ---- the direct kernel with the activation fragments requested TWO k-chunks ahead (round 3) ----------------------------------
 // EXPERIMENT (VIP_BUILD_EXPERIMENTS=1, selected per call with VIP_PWK_PF2=1) - a NEGATIVE result, kept for the record.
@@ -1650,6 +1834,25 @@ static int conv2d_impl(const void* x, const void* gate, int y_lo_off, const void
             // (a 64 x 256 wave tile at one wave per SIMD - NG = 4 - measured 15-40 % slower than NG = 2 at two)
             static const int xl_min_k = getenv("VIP_PWK_XLK") ? atoi(getenv("VIP_PWK_XLK")) : 768;
             // (gated convolutions: only the direct kernel carries the gate pipeline - their deep-K cases are small launches)
+            // short K, wide N: the activation-resident kernel (pwx_kernel) - an EXPERIMENT, off unless VIP_PWX=1 (read per call: its tests
+            // set it).  Measured per shape against pwk_direct_kernel (profiles/r04_pwx_vs_pwk_direct.log): a wash on the fp16 storage
+            // (sum of ten ensemble shapes 566 vs 564 us) and 7-35 % slower on the packed storage, where K = 256 needs 128 fragment
+            // registers, leaves 16 pixels per wave and makes every 64-pixel workgroup stream all of W out of L2.  The K <= 256 layers are
+            // not bound by the fill / drain this kernel removes: their GELU / residual epilogues issue 7 VALU instructions per MFMA.
+            const char* pwx_env = getenv("VIP_PWX");
+            const int pwx_on = pwx_env ? atoi(pwx_env) : 0;
+            if (pwx_on && !gate && cout_g >= 256 && a.K <= (H2 ? 512 : 256) && a.K > 64 && M >= 16384 && a.x_span_bytes < 0xFFFF0000L - 2L * a.K) {
+                const int ksc = (a.K + 63) >> 6;
+                if (H2) {
+                    if (ksc <= 4) VIP_PICK("pwx_kernel", (launch_pwx<4, 2>(a, mode, s)));
+                    if (ksc <= 6) VIP_PICK("pwx_kernel", (launch_pwx<6, 1>(a, mode, s)));      // (32 pixels per wave spill at 96 fragment registers)
+                    VIP_PICK("pwx_kernel", (launch_pwx<8, 1>(a, mode, s)));
+                } else {
+                    if (ksc <= 2) VIP_PICK("pwx_kernel", (launch_pwx<2, 2>(a, mode, s)));
+                    if (ksc <= 3) VIP_PICK("pwx_kernel", (launch_pwx<3, 2>(a, mode, s)));
+                    VIP_PICK("pwx_kernel", (launch_pwx<4, 2>(a, mode, s)));
+                }
+            }
             if ((a.K < xl_min_k || gate) && a.x_span_bytes < 0xFFFF0000L - 2L * a.K)
                 VIP_PICK("pwk_direct_kernel", cout_g <= 64 ? launch_pwk_direct<1>(a, mode, s) : launch_pwk_direct<2>(a, mode, s));
             VIP_REQUIRE(!gate, VIP_ERR_UNSUPPORTED, "vip_conv2d_gated_nhwc_f16: input tensor too large (4 GB - 2K)");
