@@ -6,8 +6,14 @@ from vipcup_amd import ops
 M, N, K = (int(v) for v in sys.argv[1:4])
 act = sys.argv[4] if len(sys.argv) > 4 and sys.argv[4] != "none" else None
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
-x = torch.randn((M, K), dtype=torch.float16, device="cuda")
-cw = ops.make_dense_weight(torch.randn((K, N)) * 0.05, torch.zeros(N))
+STRICT = os.environ.get("VIP_BENCH_PREC", "fast") == "strict"        # the packed storage (h2 kernels)
+if STRICT:
+    x = ops.pack_h2(torch.randn((M, K), device="cuda"))
+    with ops.precision("strict"):
+        cw = ops.make_dense_weight(torch.randn((K, N)) * 0.05, torch.zeros(N))
+else:
+    x = torch.randn((M, K), dtype=torch.float16, device="cuda")
+    cw = ops.make_dense_weight(torch.randn((K, N)) * 0.05, torch.zeros(N))
 for _ in range(2):
     ops.dense(x, cw, act=act)
 torch.cuda.synchronize()

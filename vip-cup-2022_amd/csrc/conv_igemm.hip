@@ -88,12 +88,20 @@ __device__ __forceinline__ void h2_store8(const ConvArgs& a, const f32x4& q0, co
 #pragma unroll
     for (int e = 0; e < 4; ++e) p[e] = vip_act2<ACT>(p[e] * a.out_scale);
     if constexpr (RES) {
-        U4H8 rh, rl;
-        rh.u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rb_res, roff, 0, 0));
-        rl.u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rb_res, roff + 16u, 0, 0));
+        // residual (hi, lo) pairs joined straight into the accumulators: v_fma_mix_f32 takes the fp16 half as an operand (p += hi; p += lo:
+        // 4 instructions per pair against 4 conversions + 2 packed adds)
+        const uint4 rh = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rb_res, roff, 0, 0));
+        const uint4 rl = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rb_res, roff + 16u, 0, 0));
+        const unsigned rhw[4] = {rh.x, rh.y, rh.z, rh.w}, rlw[4] = {rl.x, rl.y, rl.z, rl.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            p[e] += (f32x2){(float)rh.e[2 * e], (float)rh.e[2 * e + 1]} + (f32x2){(float)rl.e[2 * e], (float)rl.e[2 * e + 1]};
+        for (int e = 0; e < 4; ++e) {
+            float px = p[e].x, py = p[e].y;
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(px) : "v"(rhw[e]));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(py) : "v"(rhw[e]));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(px) : "v"(rlw[e]));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(py) : "v"(rlw[e]));
+            p[e] = (f32x2){px, py};
+        }
     }
     if constexpr (POST == 1) {
 #pragma unroll
@@ -102,26 +110,26 @@ __device__ __forceinline__ void h2_store8(const ConvArgs& a, const f32x4& q0, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) p[e] = (f32x2){vip_act_strict(p[e].x, a.act_post), vip_act_strict(p[e].y, a.act_post)};
     }
-    U4H8 oh, ol;
-    f32x2 tot = {0.f, 0.f};
-    float mx = 0.f;
+    // split: hi = rn16(v) (v_cvt_pk_f16_f32), lo = rn16(v - hi) as ONE v_fma_mixlo / mixhi_f16 per value (fma(hi, -1, v) is exact, so
+    // this is the same single rounding as converting the fp32 difference).  Range check on the hi halves: a value beyond the fp16 range
+    // (or a NaN) converts to an all-ones exponent, and as unsigned 16-bit integers |NaN| > |Inf| > every finite value - one packed
+    // integer max per pair, one test per store
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    unsigned hw[4], lw[4];
+    u16x2 mx = {0, 0};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const f16x2 h = __builtin_convertvector(p[e], f16x2);
-        const f32x2 d = p[e] - __builtin_convertvector(h, f32x2);
-        const f16x2 l = __builtin_convertvector(d, f16x2);
-        oh.e[2 * e] = h.x; oh.e[2 * e + 1] = h.y;
-        ol.e[2 * e] = l.x; ol.e[2 * e + 1] = l.y;
-        tot += p[e];                                     // a NaN or an Inf anywhere makes the sum non-finite (finite values cannot overflow it)
-        mx = fmaxf(mx, fmaxf(fabsf(p[e].x), fabsf(p[e].y)));
+        hw[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(p[e], f16x2));
+        const float px = p[e].x, py = p[e].y;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lw[e]) : "v"(hw[e]), "v"(px));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw[e]) : "v"(hw[e]), "v"(py));
+        mx = __builtin_elementwise_max(mx, __builtin_bit_cast(u16x2, hw[e] & 0x7FFF7FFFu));
     }
     typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, oh.u), rb_y, off, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ol.u), rb_y, off + 16u, 0, 0);
-    float tx = tot.x, ty = tot.y;
-    asm volatile("" : "+v"(tx), "+v"(ty));       // two scalars: hipcc otherwise forms the horizontal sum as a half-SWAPPED v_pk_add_f32
-    const float ts = tx + ty;                    // (op_sel:[0,1] op_sel_hi:[1,0]) - the form tools/isa_lint.py keeps out of the library
-    if (a.status && off != OOB2 && (!(mx <= VIP_H2_MAX) || !(fabsf(ts) <= 3.0e38f))) *a.status = VIP_H2_OVERFLOW;
+    const u32x4 oh = {hw[0], hw[1], hw[2], hw[3]}, ol = {lw[0], lw[1], lw[2], lw[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(oh, rb_y, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(ol, rb_y, off + 16u, 0, 0);
+    if (a.status && off != OOB2 && (mx.x >= 0x7C00 || mx.y >= 0x7C00)) *a.status = VIP_H2_OVERFLOW;
 }
 
 __device__ __forceinline__ int swz_x(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }

@@ -220,14 +220,17 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_h2_kernel(MlpH2Args a) {
 #pragma unroll
                     for (int j = 0; j < 4; j += 2) {
                         const f32x2 v = vip_gelu2((f32x2){acc1[t][p][j], acc1[t][p][j + 1]} * a.os1);
-                        const f16x2 h = __builtin_convertvector(v, f16x2);
-                        const f32x2 d = v - __builtin_convertvector(h, f32x2);
-                        const f16x2 l = __builtin_convertvector(d, f16x2);
-                        hh[p].e[t * 4 + j] = h.x;
-                        hh[p].e[t * 4 + j + 1] = h.y;
-                        hl[p].e[t * 4 + j] = l.x;
-                        hl[p].e[t * 4 + j + 1] = l.y;      // (a hidden value beyond the fp16 range becomes Inf here and NaN / Inf in y: the
-                    }                                      //  range check of the outputs below reports it)
+                        // hi = rn16(v); lo = rn16(v - hi) as one v_fma_mixlo / mixhi_f16 per value (fma(hi, -1, v) is exact: the same
+                        // single rounding as converting the fp32 difference).  A hidden value beyond the fp16 range becomes Inf here and
+                        // NaN / Inf in y: the range check of the outputs below reports it
+                        const unsigned hw = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+                        unsigned lw;
+                        const float vx = v.x, vy = v.y;
+                        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lw) : "v"(hw), "v"(vx));
+                        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lw) : "v"(hw), "v"(vy));
+                        reinterpret_cast<unsigned*>(&hh[p])[(t * 4 + j) >> 1] = hw;
+                        reinterpret_cast<unsigned*>(&hl[p])[(t * 4 + j) >> 1] = lw;
+                    }
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 U4H8 wh, wl;
