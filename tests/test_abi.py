@@ -82,6 +82,47 @@ def test_argument_checks_do_not_need_a_gpu():
     assert st == -1
 
 
+def test_packed_strict_entry_points_check_arguments_without_a_gpu():
+    """the round-4 entry points of the packed strict storage: shape support is a pure function, bad arguments are refused with a message"""
+    import ctypes as C
+    from vipcup_amd import _abi
+    lib = _abi.lib()
+    p = C.c_void_p(64)
+    # fused MLP: C = 64 / 96 / 128, GELU, hidden % 32 == 0, enough tokens
+    assert lib.vip_mlp_fused_supported_h2(100000, 96, 384, 3) == 1 and lib.vip_mlp_fused_supported_h2(100000, 128, 512, 3) == 1
+    assert lib.vip_mlp_fused_supported_h2(100000, 192, 768, 3) == 0 and lib.vip_mlp_fused_supported_h2(100000, 96, 384, 2) == 0
+    assert lib.vip_mlp_fused_supported_h2(100, 96, 384, 3) == 0 and lib.vip_mlp_fused_supported_h2(100000, 96, 400, 3) == 0
+    st = lib.vip_mlp_fused_h2(p, None, None, 0.0, p, None, 1.0, p, None, 1.0, None, p, 100000, 192, 768, 192, 384, 1536, 192, 0, 3, None, None)
+    assert st == -3 and b"unsupported" in lib.vip_last_error()
+    st = lib.vip_mlp_fused_h2(p, p, None, 1e-6, p, None, 1.0, p, None, 1.0, None, p, 100000, 96, 384, 96, 192, 768, 96, 0, 3, None, None)
+    assert st == -1 and b"ln_gamma" in lib.vip_last_error()
+    st = lib.vip_mlp_fused_h2(p, None, None, 0.0, p, None, 0.0, p, None, 1.0, None, p, 100000, 96, 384, 96, 192, 768, 96, 0, 3, None, None)
+    assert st == -1 and b"out_scale" in lib.vip_last_error()
+    st = lib.vip_mlp_fused_h2(p, None, None, 0.0, p, None, 1.0, p, None, 1.0, None, p, 100000, 96, 384, 96, 100, 768, 96, 0, 3, None, None)
+    assert st == -2                                                  # weight rows of 16 halfs
+    # LDS-staged depthwise: k = 3 / 5 / 7, C % 8 == 0, tensors below 4 GiB
+    assert lib.vip_dwconv2d_s1_supported_h2(256, 99, 99, 96, 7, 99, 99) == 1 and lib.vip_dwconv2d_s1_supported_h2(256, 7, 7, 1632, 5, 7, 7) == 1
+    assert lib.vip_dwconv2d_s1_supported_h2(256, 99, 99, 96, 4, 99, 99) == 0 and lib.vip_dwconv2d_s1_supported_h2(256, 99, 99, 100, 7, 99, 99) == 0
+    assert lib.vip_dwconv2d_s1_supported_h2(4096, 200, 200, 96, 7, 200, 200) == 0          # 4 B x 15.7 G elements
+    st = lib.vip_dwconv2d_s1_h2(p, p, None, p, 2, 14, 14, 32, 9, 4, 4, 14, 14, 0, None, None)
+    assert st == -3 and b"k = 3 / 5 / 7" in lib.vip_last_error()
+    st = lib.vip_dwconv2d_s1_h2(p, None, None, p, 2, 14, 14, 32, 3, 1, 1, 14, 14, 0, None, None)
+    assert st == -1
+    st = lib.vip_dw_filter_quad_major(p, p, 3, 30, None)
+    assert st == -1 and b"multiple of 4" in lib.vip_last_error()
+    # gated conv on the packed storage: pointwise only, the gate spans the whole input channel axis
+    d = _abi.ConvDesc(B=1, H=8, W=8, Cin=16, Cout=16, kh=3, kw=3, sh=1, sw=1, pt=1, pl=1, Ho=8, Wo=8, groups=1, ldx=16,
+                      cin_off=0, ldy=16, cout_off=0, ldr=0, res_off=0, ldw=288, act_pre=0, act_post=0)
+    st = lib.vip_conv2d_gated_nhwc_h2(p, p, p, None, None, p, C.byref(d), 1.0, None, None)
+    assert st == -3 and b"gate" in lib.vip_last_error()
+    st = lib.vip_conv2d_gated_nhwc_h2(p, None, p, None, None, p, C.byref(d), 1.0, None, None)
+    assert st == -1
+    d = _abi.ConvDesc(B=1, H=8, W=8, Cin=16, Cout=16, kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, Ho=8, Wo=8, groups=1, ldx=32,
+                      cin_off=0, ldy=16, cout_off=0, ldr=0, res_off=0, ldw=32, act_pre=0, act_post=0)
+    st = lib.vip_conv2d_gated_nhwc_h2(p, p, p, None, None, p, C.byref(d), 1.0, None, None)
+    assert st == -3 and b"ldx = Cin" in lib.vip_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from vipcup_amd import _abi
     monkeypatch.setattr(_abi, "_lib", None)

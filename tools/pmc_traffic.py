@@ -8,7 +8,10 @@ FAMILIES = {"conv_igemm_kernel": ("conv_igemm_kernel",), "pw_gemm_kernel": ("pw_
             "pwk_gemm_kernel": ("pwk_gemm_kernel", "pwk_direct_kernel"), "gemm8p_kernel": ("gemm8p_kernel",), "rows_gemm_kernel": ("rows_gemm_kernel",), "mlp_fused_kernel": ("mlp_fused_kernel",),
             "mlp_stream_kernel": ("mlp_stream_kernel",), "window_attn_kernel": ("window_attn_kernel", "window_attn_pipe_kernel"),
             "dwconv": ("dwconv_tile_kernel", "dwconv_kernel"), "layernorm": ("layernorm_kernel",),
-            "scale_add_act": ("scale_add_act_kernel",), "gap": ("gap_kernel",), "se_gate": ("se_gate_kernel",)}
+            "scale_add_act": ("scale_add_act_kernel",), "gap": ("gap_kernel",), "se_gate": ("se_gate_kernel",),
+            # kernels of the packed strict step (the GEMM names above are shared: its summary is a separate file)
+            "mlp_h2_kernel": ("mlp_h2_kernel",), "dwconv_lds_h2_kernel": ("dwconv_lds_h2_kernel",), "attn_h2_kernel": ("attn_h2_kernel",),
+            "h2_layernorm_kernel": ("h2_layernorm_kernel",)}
 
 
 def load(d, counter):

@@ -29,6 +29,12 @@ PMC_ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-resident-leg --no
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $PMC_ARGS > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $PMC_ARGS > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 python3 tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/hbm_traffic_pmc.json > $OUT/pmc_traffic.log 2>&1
+# 5. + 6. the same two counters over the STRICT step                                            -> hbm_traffic_pmc_strict.json
+SPMC_ARGS="bench.py --precision strict --steps 2 --warmup 1 --no-cpu-baseline --no-resident-leg --no-batch-sweep --distinct-batches 2"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_s -- python3 $SPMC_ARGS > $OUT/pmc_fetch_s.json 2> $OUT/pmc_fetch_s.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_s -- python3 $SPMC_ARGS > $OUT/pmc_write_s.json 2> $OUT/pmc_write_s.err
+python3 tools/pmc_traffic.py $OUT/pmc_fetch_s $OUT/pmc_write_s $OUT/hbm_traffic_pmc_strict.json > $OUT/pmc_traffic_strict.log 2>&1
+rm -rf $OUT/pmc_fetch_s $OUT/pmc_write_s
 # the raw traces are large: keep the summaries only
 rm -rf $OUT/streams $OUT/serial $OUT/pmc_fetch $OUT/pmc_write
 ls -la $OUT

@@ -113,7 +113,14 @@ __global__ __launch_bounds__(256, 2) void dwconv_lds_h2_kernel(DwLdsArgs a, cons
 
     // a contiguous run of items per workgroup, the 16-channel blocks of one region group back to back: the descriptors of the group are
     // computed once and the two 64-byte halves of a pixel's 128-byte line are read by the same workgroup within microseconds (L2 hits)
-    const long it0 = a.n_items * blockIdx.x / gridDim.x, it1 = a.n_items * (blockIdx.x + 1) / gridDim.x;
+    // (workgroups are dealt round-robin to the 8 XCDs: renumbered so that each XCD owns one contiguous band of runs - neighbouring
+    // regions, which share halo rows, then meet in ONE L2; PMC before: 2.15 bytes fetched from HBM per byte written)
+    int bid = blockIdx.x;
+    if (gridDim.x >= 8) {
+        const int q = gridDim.x >> 3, r = gridDim.x & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long it0 = a.n_items * bid / gridDim.x, it1 = a.n_items * (bid + 1) / gridDim.x;
     int grp_cur = (int)(it0 / a.n_cblk), cblk = (int)(it0 - (long)grp_cur * a.n_cblk);
 
     auto group_meta = [&](int group, int slot) {     // threads 0 .. IMG-1 describe the group's sub-regions

@@ -386,8 +386,10 @@ def _pmc_traffic(fam: str):
     import json
     import os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    strict = fam.startswith("h2:")        # the packed strict step has a PMC summary of its own (same kernel names, another code object)
+    fam = fam[3:] if strict else fam
     key = "pwk_gemm_kernel" if fam == "pwk_*" else fam
-    for path in sorted(glob.glob(os.path.join(root, "r*_hbm_traffic_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(root, "r*_hbm_traffic_pmc_strict.json" if strict else "r*_hbm_traffic_pmc.json")), reverse=True):
         try:
             d = json.load(open(path))
             # only a PMC summary taken from THIS kernel build counts: the summary records the library's source digest
