@@ -44,6 +44,12 @@ def _victims():
     with ops.precision("strict"):
         cwh = ops.make_conv_weight(wsk, torch.zeros(256))
         f1h = ops.make_dense_weight(torch.randn(96, 384, generator=g) / 10, torch.zeros(384))
+        f2h = ops.make_dense_weight(torch.randn(384, 96, generator=g) / 20, torch.zeros(96))
+        cw8h = ops.make_dense_weight(torch.randn(768, 256, generator=g) / 28, torch.zeros(256))
+    lnh = (torch.ones(96).cuda(), torch.zeros(96).cuda(), 1e-6)
+    gateh = ops.pack_h2(torch.rand(64, 256, generator=g).cuda())
+    dw7 = ops.make_dw_weight(torch.randn(7, 7, 256, 1, generator=g) / 7)
+    x8h = ops.pack_h2(torch.randn(36864, 768, generator=g).cuda())
     xs32 = torch.randn(64, 14, 14, 256, generator=g).cuda()
     xsh = ops.pack_h2(xs32)
     xmh = ops.pack_h2(torch.randn(64 * 56 * 56, 96, generator=g).cuda())
@@ -88,6 +94,11 @@ def _victims():
         "strict window_attn ws14 (h2)": lambda: ops.window_attention(qkv14h, None, tab14, 8, 14, 32 ** -0.5),
         "strict window_attn ws7 (h2)": lambda: ops.window_attention(qkv7h, None, tab7, 2, 7, 32 ** -0.5),
         "strict mhsa (h2)": lambda: ops.mhsa(qkvmh, 6, 0.125),
+        # round 4: the fused LayerNorm-MLP, the gate inside the GEMM operand, the LDS-staged depthwise kernel, gemm8p on the packed storage
+        "strict mlp fused (h2)": lambda: ops.mlp(xmh, f1h, f2h, act="gelu", residual=xmh, ln=lnh),
+        "strict gated conv (h2)": lambda: ops.conv2d(xsh, cwh, gate=gateh),
+        "strict dwconv 7x7 (h2 lds)": lambda: ops.dwconv2d(xsh, dw7, None, 7, 1, (3, 3, 3, 3)),
+        "strict dense (h2 gemm8p)": lambda: ops.dense(x8h, cw8h),
     }
 
 
