@@ -271,6 +271,84 @@ def test_dwconv_lds_h2(B, H, W, C, k, pad, act, report):
     check(report, f"dwconv(lds) {B}x{H}x{W}x{C} k{k}", got, R.act(R.dwconv2d(x, w, b, 1, pad), act))
 
 
+def test_dwconv_lds_h2_fuzz(report):
+    """60 random shapes (maps from 1 x 1 to 130 x 70, 8 ... 200 channels, ragged batches, every padding up to k - 1) through the LDS-staged
+    kernel's own entry point against the plain strict kernel (vip_dwconv2d_nhwc_h2 with the tile / LDS paths bypassed is not reachable
+    per call, so the reference here is the fp32 oracle on the unpacked input) - the lane packings the host picks are data-dependent"""
+    import random
+    ops = _ops()
+    lib = ops._abi.lib()
+    rnd = random.Random(1234)
+    worst = 0.0
+    for it in range(60):
+        k = rnd.choice([3, 5, 7])
+        H, W = rnd.choice([(1, 1), (2, 3), (7, 7), (5, 19), (14, 14), (13, 29), (33, 17), (64, 9), (130, 70), (49, 49)])
+        C = 8 * rnd.randint(1, 25)
+        B = rnd.choice([1, 2, 3, 5, 17])
+        pt, pl = rnd.randint(0, k - 1), rnd.randint(0, k - 1)
+        pb, pr = rnd.randint(0, k - 1), rnd.randint(0, k - 1)
+        Ho, Wo = H + pt + pb - k + 1, W + pl + pr - k + 1
+        if Ho <= 0 or Wo <= 0:
+            continue
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn(B, H, W, C, generator=g)
+        w = torch.randn(k, k, C, 1, generator=g) / k
+        b = torch.randn(C, generator=g) * 0.1
+        act = rnd.choice([None, "relu", "silu", "gelu"])
+        assert lib.vip_dwconv2d_s1_supported_h2(B, H, W, C, k, Ho, Wo) == 1
+        got = ops.dwconv2d(A(x, "strict"), ops.make_dw_weight(w), dev(b), k, 1, (pt, pb, pl, pr), act=act)
+        ops.h2_check("dwconv fuzz")
+        ref = R.act(R.dwconv2d(x, w, b, 1, (pt, pb, pl, pr)), act)
+        err = (ops.unpack_h2(got).cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-6)
+        worst = max(worst, err)
+        assert err <= TOL_OP, (it, B, H, W, C, k, (pt, pb, pl, pr), act, err)
+    report(f"[strict-ops] dwconv(lds) fuzz: worst rel err {worst:.3e} over 60 random shapes")
+
+
+def test_mlp_and_gated_conv_h2_fuzz(report):
+    """random token counts / widths through the fused MLP and random shapes through the gated GEMM, against the fp32 oracle"""
+    import random
+    ops = _ops()
+    rnd = random.Random(99)
+    worst = 0.0
+    for it in range(8):
+        C = rnd.choice([64, 96, 128])
+        hid = 32 * rnd.randint(2, 16)
+        M = 8192 + rnd.randint(0, 700)
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn(M, C, generator=g)
+        k1, b1 = torch.randn(C, hid, generator=g) / math.sqrt(C), torch.randn(hid, generator=g) * 0.1
+        k2, b2 = torch.randn(hid, C, generator=g) / math.sqrt(hid), torch.randn(C, generator=g) * 0.1
+        with ops.precision("strict"):
+            fc1, fc2 = ops.make_dense_weight(k1, b1), ops.make_dense_weight(k2, b2)
+        xa = A(x, "strict")
+        got = ops.mlp(xa, fc1, fc2, act="gelu", residual=xa)
+        ops.h2_check("mlp fuzz")
+        ref = x + R.dense(R.act(R.dense(x, k1, b1), "gelu"), k2, b2)
+        err = (ops.unpack_h2(got).cpu() - ref).abs().max().item() / ref.abs().max().item()
+        worst = max(worst, err)
+        assert err <= TOL_OP, ("mlp", it, M, C, hid, err)
+    for it in range(16):
+        B, HW = rnd.choice([(1, 1), (3, 7), (2, 14), (9, 5), (1, 56), (33, 3)])
+        Cin, Cout = 8 * rnd.randint(1, 60), 8 * rnd.randint(1, 40)
+        g = torch.Generator().manual_seed(100 + it)
+        x = torch.randn(B, HW, HW, Cin, generator=g)
+        gate = torch.rand(B, Cin, generator=g) * 1.5
+        w, b = torch.randn(1, 1, Cin, Cout, generator=g) / math.sqrt(Cin), torch.randn(Cout, generator=g) * 0.1
+        res = rnd.random() < 0.5
+        r = torch.randn(B, HW, HW, Cout, generator=g) if res else None
+        act = None if res else rnd.choice([None, "silu", "relu"])
+        with ops.precision("strict"):
+            cw = ops.make_conv_weight(w, b)
+        got = ops.conv2d(A(x, "strict"), cw, act=act, gate=A(gate, "strict"), residual=A(r, "strict") if res else None)
+        ops.h2_check("gated fuzz")
+        ref = R.act(R.conv2d(x * gate[:, None, None, :], w, b), act) + (r if res else 0)
+        err = (ops.unpack_h2(got).cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-6)
+        worst = max(worst, err)
+        assert err <= TOL_OP, ("gated", it, B, HW, Cin, Cout, act, res, err)
+    report(f"[strict-ops] fused MLP / gated conv fuzz: worst rel err {worst:.3e}")
+
+
 def test_dwconv_lds_h2_identity_is_exact():
     """a centre-tap-only filter returns the input VALUES exactly (the sign of a zero lo term may differ) - small magnitudes included, whose
     lo terms are fp16 subnormals (the kernel joins hi + lo with v_fma_mix_f32; a flushed subnormal would show here and nowhere in the
