@@ -60,9 +60,15 @@ __device__ __forceinline__ int v_slot(int row, int dt) {
     else return dt ^ ((row >> 2) & 1);
 }
 
+// threads per workgroup: the hd = 64 item (ViT, 197 tokens) needs 115 KB of LDS, one workgroup per CU - with 4 waves that is ONE wave per
+// SIMD and nothing to hide a wait behind; 8 waves (two per SIMD, 196 registers each) share the 13 query tiles instead
+template <int HD>
+constexpr int attn_h2_threads() { return HD == 64 ? 512 : 256; }
+
 template <int HD, int WS>
-__global__ __launch_bounds__(256, HD == 64 ? 1 : 2) void attn_h2_kernel(AttnH2Args a) {
+__global__ __launch_bounds__(attn_h2_threads<HD>(), 2) void attn_h2_kernel(AttnH2Args a) {
     using Cfg = AttnCfg<HD, WS>;
+    constexpr int NT = attn_h2_threads<HD>();
     constexpr int RP = Cfg::RP, NKT = Cfg::NKT, ROWB = Cfg::ROWB, KS = Cfg::KS, DT = Cfg::DT, CPR = HD / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_hi = smem;
@@ -101,13 +107,13 @@ __global__ __launch_bounds__(256, HD == 64 ? 1 : 2) void attn_h2_kernel(AttnH2Ar
     // ---- stage K, V: slot = (array, row, 8-channel group) -> one 32-byte (hi, lo) pair from global, two 16-byte LDS writes ----
     {
         constexpr int NSLOT = 2 * RP * CPR;
-        constexpr int NIT = (NSLOT + 255) / 256;
+        constexpr int NIT = (NSLOT + NT - 1) / NT;
         constexpr int BATCH = 7;
         for (int it0 = 0; it0 < NIT; it0 += BATCH) {
             uint4 sh[BATCH], sl[BATCH];
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
-                const int s = tid + (it0 + u) * 256;
+                const int s = tid + (it0 + u) * NT;
                 const int arr = s / (RP * CPR);
                 const int rem = s - arr * (RP * CPR);
                 const int row = rem / CPR, cg = rem - row * CPR;
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 1 : 2) void attn_h2_kernel(AttnH2Ar
             }
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
-                const int s = tid + (it0 + u) * 256;
+                const int s = tid + (it0 + u) * NT;
                 if (it0 + u < NIT && s < NSLOT) {
                     const int arr = s / (RP * CPR);
                     const int rem = s - arr * (RP * CPR);
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 1 : 2) void attn_h2_kernel(AttnH2Ar
         }
         if constexpr (WS > 0) {                             // this head's table column, pre-divided by the scale (the MFMA C operand)
             const float inv = 1.0f / a.scale;
-            for (int i = tid; i < Cfg::TBL; i += 256) tbl[i] = a.table[(long)i * a.heads + head] * inv;
+            for (int i = tid; i < Cfg::TBL; i += NT) tbl[i] = a.table[(long)i * a.heads + head] * inv;
         }
     }
     __syncthreads();
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 1 : 2) void attn_h2_kernel(AttnH2Ar
     const int nks = (nkt + 1) >> 1;                         // 32-key PV steps
     bool bad = false;
 
-    for (int qt = wave; qt < nkt; qt += 4) {
+    for (int qt = wave; qt < nkt; qt += NT / 64) {
         const int qn = qt * 16 + l15;
         const bool qok = qn < N;
         // ---- Q fragments (hi, lo) of this lane's query: channels ks * 32 + g * 8 .. + 7 of the head ----
@@ -285,7 +291,7 @@ int launch_attn_h2(const AttnH2Args& a, long items, hipStream_t s, const char* w
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_h2_kernel<HD, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM);
         attr = true;
     }
-    hipLaunchKernelGGL((attn_h2_kernel<HD, WS>), dim3((unsigned)items), dim3(256), Cfg::SMEM, s, a);
+    hipLaunchKernelGGL((attn_h2_kernel<HD, WS>), dim3((unsigned)items), dim3(attn_h2_threads<HD>()), Cfg::SMEM, s, a);
     return vip_launch_status(who);
 }
 
