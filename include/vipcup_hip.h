@@ -426,6 +426,14 @@ int vip_dw_filter_quad_major(const float* w, float* w_quad, int k, int C, void* 
 int vip_dwconv2d_s1_supported_h2(int B, int H, int W, int C, int k, int Ho, int Wo);
 int vip_dwconv2d_s1_h2(const void* x, const float* w_quad, const float* bias, void* y, int B, int H, int W, int C, int k, int pt, int pl,
                        int Ho, int Wo, int act, int* status, void* stream);
+/* The pooling form (strict counterpart of vip_dwconv2d_pool_nhwc_f16 + vip_se_gate_pooled_f16): also leaves partials[B][parts][C] fp32,
+ * the sums of the activated outputs over `parts` = vip_dwconv2d_s1_pool_parts_h2(...) blocks of each image (0: shape not taken), from
+ * which vip_se_gate_pooled_h2 finishes the squeeze-excite mean without reading the map again; fixed summation order. */
+int vip_dwconv2d_s1_pool_parts_h2(int B, int H, int W, int C, int k, int Ho, int Wo);
+int vip_dwconv2d_s1_pool_h2(const void* x, const float* w_quad, const float* bias, void* y, float* partials, int parts, int B, int H, int W, int C,
+                            int k, int pt, int pl, int Ho, int Wo, int act, int* status, void* stream);
+int vip_se_gate_pooled_h2(const float* partials, int parts, const void* w1, const float* b1, float s1, const void* w2, const float* b2, float s2,
+                          void* gate, int B, int HW, int C, int Cr, int ldw1, int Cout, int ldw2, int act1, int act2, int* status, void* stream);
 /* vip_se_gate_f16 on the packed storage: gate [B][Cout] packed; w1 / w2 packed rows of W * scale (ldw in halfs), b = bias * scale,
  * s1 / s2 = 1 / scale */
 int vip_se_gate_h2(const void* x, const void* w1, const float* b1, float s1, const void* w2, const float* b2, float s2, void* gate,

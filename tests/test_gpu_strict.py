@@ -271,6 +271,40 @@ def test_dwconv_lds_h2(B, H, W, C, k, pad, act, report):
     check(report, f"dwconv(lds) {B}x{H}x{W}x{C} k{k}", got, R.act(R.dwconv2d(x, w, b, 1, pad), act))
 
 
+@pytest.mark.parametrize("B,H,W,C,k,act", [(5, 14, 14, 96, 5, "silu"), (9, 7, 7, 40, 3, "silu"), (3, 24, 20, 64, 3, "gelu"), (2, 56, 56, 24, 3, "silu"),
+                                           (2, 99, 99, 16, 7, None), (17, 13, 13, 72, 3, "silu")])
+def test_dwconv_se_pooled_h2(B, H, W, C, k, act, report):
+    """DepthwiseConv2D -> activation -> se_module with the pool's partial sums left by the depthwise kernel (vip_dwconv2d_s1_pool_h2 +
+    vip_se_gate_pooled_h2): the map and the gate against the oracle, against the two plain launches, and bit-reproducible"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + H + C + k)
+    x = torch.randn(B, H, W, C, generator=g)
+    w = torch.randn(k, k, C, 1, generator=g) / k
+    b = torch.randn(C, generator=g) * 0.1
+    Cr = max(8, C // 4 // 8 * 8)
+    k1, b1 = torch.randn(C, Cr, generator=g) / math.sqrt(C), torch.randn(Cr, generator=g) * 0.1
+    k2, b2 = torch.randn(Cr, C, generator=g) / math.sqrt(Cr), torch.randn(C, generator=g) * 0.1
+    with ops.precision("strict"):
+        fc1, fc2 = ops.make_dense_weight(k1, b1), ops.make_dense_weight(k2, b2)
+    p = k // 2
+    xa, dw, bb = A(x, "strict"), ops.make_dw_weight(w), dev(b)
+    assert ops._abi.lib().vip_dwconv2d_s1_pool_parts_h2(B, H, W, C, k, H, W) > 0
+    h, gate = ops.dwconv2d_se(xa, dw, bb, k, 1, (p, p, p, p), act, fc1, fc2, "silu", "sigmoid")
+    ops.h2_check("dwconv2d_se")
+    href = R.act(R.dwconv2d(x, w, b, 1, (p, p, p, p)), act)
+    gref = torch.sigmoid(R.dense(R.act(R.dense(href.mean((1, 2)), k1, b1), "silu"), k2, b2))
+    check(report, f"dwconv_se map {B}x{H}x{W}x{C} k{k}", h, href)
+    check(report, f"dwconv_se gate {B}x{H}x{W}x{C} k{k}", gate, gref)
+    with ops.unfused():
+        h2, gate2 = ops.dwconv2d_se(xa, dw, bb, k, 1, (p, p, p, p), act, fc1, fc2, "silu", "sigmoid")
+    assert torch.equal(h.cpu(), h2.cpu()), "the pooling form must not change the map"
+    d = (ops.unpack_h2(gate) - ops.unpack_h2(gate2)).abs().max().item()
+    report(f"[strict-ops] pooled gate vs plain gate: max_abs_diff={d:.3e}")
+    assert d <= 2e-6
+    h3, gate3 = ops.dwconv2d_se(xa, dw, bb, k, 1, (p, p, p, p), act, fc1, fc2, "silu", "sigmoid")
+    assert torch.equal(gate.cpu(), gate3.cpu()) and torch.equal(h.cpu(), h3.cpu()), "bit-reproducible"
+
+
 def test_dwconv_lds_h2_fuzz(report):
     """60 random shapes (maps from 1 x 1 to 130 x 70, 8 ... 200 channels, ragged batches, every padding up to k - 1) through the LDS-staged
     kernel's own entry point against the plain strict kernel (vip_dwconv2d_nhwc_h2 with the tile / LDS paths bypassed is not reachable

@@ -111,6 +111,9 @@ SIGNATURES = {
     "vip_dw_filter_quad_major": (_i, [_vp, _vp, _i, _i, _vp]),
     "vip_dwconv2d_s1_supported_h2": (_i, [_i] * 7),
     "vip_dwconv2d_s1_h2": (_i, [_vp, _vp, _vp, _vp] + [_i] * 10 + [_vp, _vp]),
+    "vip_dwconv2d_s1_pool_parts_h2": (_i, [_i] * 7),
+    "vip_dwconv2d_s1_pool_h2": (_i, [_vp, _vp, _vp, _vp, _vp] + [_i] * 11 + [_vp, _vp]),
+    "vip_se_gate_pooled_h2": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _f, _vp] + [_i] * 9 + [_vp, _vp]),
     "vip_se_gate_h2": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _f, _vp] + [_i] * 10 + [_vp, _vp]),
     "vip_layernorm_h2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "vip_pool2d_nhwc_h2": (_i, [_vp, _vp] + [_i] * 13 + [_vp, _vp]),

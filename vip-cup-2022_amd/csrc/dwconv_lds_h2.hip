@@ -39,6 +39,7 @@ struct DwLdsArgs {
     int n_sub;                // B * RGY * RGX sub-regions
     long n_items;             // ceil(n_sub / IMG) * n_cblk
     int* status;
+    float* partials;          // optional [n_sub][C] fp32: per sub-region sums of the outputs (the squeeze-excite pool, vip_se_gate_pooled_h2)
     int dbg;                  // experiments (VIP_DW_LDS_DBG): 1 = no math, 2 = no global stores, 4 = no patch loads
 };
 
@@ -233,6 +234,9 @@ __global__ __launch_bounds__(256, 2) void dwconv_lds_h2_kernel(DwLdsArgs a, cons
         if (quad_ok) {
             const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
             char* orow = smem + (size_t)(((quad * a.IMG + im) * a.RH + ty * T) * a.OWP + tx * 5) * 16;
+            // pooled form: this lane's sum over its pixels that exist (the tile may overhang the map)
+            const int4 mo = meta_out[cur][im];
+            float psum[4] = {0.f, 0.f, 0.f, 0.f};
             auto epi = [&](auto atag) {
                 constexpr int ACT = decltype(atag)::value;
 #pragma unroll
@@ -240,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_lds_h2_kernel(DwLdsArgs a, cons
 #pragma unroll
                     for (int ox = 0; ox < TW; ++ox) {
                         float v[4] = {acc[oy][ox][0][0] + bv.x, acc[oy][ox][0][1] + bv.y, acc[oy][ox][1][0] + bv.z, acc[oy][ox][1][1] + bv.w};
+                        const bool px_ok = lane_ok && mo.w && mo.x + ty * T + oy < a.Ho && mo.y + tx * TW + ox < a.Wo;
                         union {
                             uint4 u;
                             f16x4 q[2];
@@ -251,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void dwconv_lds_h2_kernel(DwLdsArgs a, cons
                             o.q[1][e] = (f16)(v[e] - (float)o.q[0][e]);      // exact difference, one rounding (v_fma_mixlo_f16 when the compiler folds it)
                             ov_max = fmaxf(ov_max, fabsf(v[e]));
                             ov_sum += v[e];
+                            psum[e] += px_ok ? v[e] : 0.f;
                         }
                         *reinterpret_cast<uint4*>(orow + (size_t)oy * a.OWP * 16 + ox * 16) = o.u;
                     }
@@ -261,6 +267,21 @@ __global__ __launch_bounds__(256, 2) void dwconv_lds_h2_kernel(DwLdsArgs a, cons
                 case VIP_ACT_GELU: epi(std::integral_constant<int, VIP_ACT_GELU>{}); break;
                 case VIP_ACT_SIGMOID: epi(std::integral_constant<int, VIP_ACT_SIGMOID>{}); break;
                 default: epi(std::integral_constant<int, VIP_ACT_NONE>{}); break;
+            }
+            if (a.partials) {      // workgroup-uniform.  Segmented sum over the lanes of a sub-region, fixed order (bit-reproducible):
+                const int seg = lane_ok ? lane - im * per : 0;      // after the step of width d, lane i holds the sum of lanes [i, i + 2d) of its segment
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = __shfl_down(psum[e], d, 64);
+                    if (lane_ok && seg + d < per) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) psum[e] += t[e];
+                    }
+                }
+                if (lane_ok && seg == 0 && mo.w)
+                    *reinterpret_cast<float4*>(a.partials + ((long)grp_cur * a.IMG + im) * a.C + c0) = make_float4(psum[0], psum[1], psum[2], psum[3]);
             }
         }
         __syncthreads();
@@ -370,8 +391,35 @@ extern "C" int vip_dwconv2d_s1_supported_h2(int B, int H, int W, int C, int k, i
     return pick_config(B, Ho, Wo, k, a) ? 1 : 0;
 }
 
+static int dwconv_s1_h2_impl(const void* x, const float* w_quad, const float* bias, void* y, float* partials, int B, int H, int W, int C, int k,
+                             int pt, int pl, int Ho, int Wo, int act, int* status, void* stream);
+
 extern "C" int vip_dwconv2d_s1_h2(const void* x, const float* w_quad, const float* bias, void* y, int B, int H, int W, int C, int k, int pt, int pl,
                                   int Ho, int Wo, int act, int* status, void* stream) {
+    return dwconv_s1_h2_impl(x, w_quad, bias, y, nullptr, B, H, W, C, k, pt, pl, Ho, Wo, act, status, stream);
+}
+
+/* The pooling form: also writes partials[B][parts][C] (fp32), the sums of the (activated) outputs over `parts` =
+ * vip_dwconv2d_s1_pool_parts_h2 blocks of each image - what vip_se_gate_pooled_h2 finishes the squeeze-excite mean from, so the gate
+ * kernel does not read the map again.  Fixed summation order: bit-reproducible. */
+extern "C" int vip_dwconv2d_s1_pool_parts_h2(int B, int H, int W, int C, int k, int Ho, int Wo) {
+    if (!vip_dwconv2d_s1_supported_h2(B, H, W, C, k, Ho, Wo)) return 0;
+    DwLdsArgs a;
+    if (!pick_config(B, Ho, Wo, k, a)) return 0;
+    return a.RGY * a.RGX;
+}
+
+extern "C" int vip_dwconv2d_s1_pool_h2(const void* x, const float* w_quad, const float* bias, void* y, float* partials, int parts, int B, int H,
+                                       int W, int C, int k, int pt, int pl, int Ho, int Wo, int act, int* status, void* stream) {
+    VIP_REQUIRE(partials, VIP_ERR_BAD_ARG, "vip_dwconv2d_s1_pool_h2: null partials");
+    VIP_REQUIRE(parts > 0 && parts == vip_dwconv2d_s1_pool_parts_h2(B, H, W, C, k, Ho, Wo), VIP_ERR_BAD_ARG,
+                "vip_dwconv2d_s1_pool_h2: partials sized for %d rows per image, the kernel writes %d", parts,
+                vip_dwconv2d_s1_pool_parts_h2(B, H, W, C, k, Ho, Wo));
+    return dwconv_s1_h2_impl(x, w_quad, bias, y, partials, B, H, W, C, k, pt, pl, Ho, Wo, act, status, stream);
+}
+
+static int dwconv_s1_h2_impl(const void* x, const float* w_quad, const float* bias, void* y, float* partials, int B, int H, int W, int C, int k,
+                             int pt, int pl, int Ho, int Wo, int act, int* status, void* stream) {
     VIP_REQUIRE(x && w_quad && y, VIP_ERR_BAD_ARG, "vip_dwconv2d_s1_h2: null pointer");
     VIP_REQUIRE(pt >= 0 && pl >= 0 && (unsigned)act <= 4u, VIP_ERR_BAD_ARG, "vip_dwconv2d_s1_h2: negative padding or unknown activation");
     VIP_REQUIRE(vip_dwconv2d_s1_supported_h2(B, H, W, C, k, Ho, Wo), VIP_ERR_UNSUPPORTED,
@@ -383,6 +431,7 @@ extern "C" int vip_dwconv2d_s1_h2(const void* x, const float* w_quad, const floa
     a.x = (const char*)x; a.w = w; a.bias = bias; a.y = (char*)y;
     a.B = B; a.H = H; a.W = W; a.C = C; a.pt = pt; a.pl = pl; a.Ho = Ho; a.Wo = Wo; a.act = act;
     a.status = status;
+    a.partials = partials;
     a.dbg = getenv("VIP_DW_LDS_DBG") ? atoi(getenv("VIP_DW_LDS_DBG")) : 0;
     if (!pick_config(B, Ho, Wo, k, a)) return VIP_ERR_UNSUPPORTED;
     a.n_cblk = (C + 15) / 16;

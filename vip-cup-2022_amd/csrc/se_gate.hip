@@ -220,6 +220,29 @@ extern "C" int vip_se_gate_h2(const void* x, const void* w1, const float* b1, fl
     return vip_launch_status("vip_se_gate_h2");
 }
 
+/* vip_se_gate_h2 from pooled partial sums (vip_dwconv2d_s1_pool_h2): partials [B][parts][C] fp32, gate packed [B][Cout]. */
+extern "C" int vip_se_gate_pooled_h2(const float* partials, int parts, const void* w1, const float* b1, float s1, const void* w2, const float* b2,
+                                     float s2, void* gate, int B, int HW, int C, int Cr, int ldw1, int Cout, int ldw2, int act1, int act2,
+                                     int* status, void* stream) {
+    VIP_REQUIRE(partials && w1 && w2 && gate, VIP_ERR_BAD_ARG, "vip_se_gate_pooled_h2: null pointer");
+    VIP_REQUIRE(B > 0 && HW > 0 && C > 0 && Cr > 0 && Cout > 0 && parts > 0 && s1 > 0.f && s2 > 0.f, VIP_ERR_BAD_ARG,
+                "vip_se_gate_pooled_h2: non-positive dimension or scale");
+    VIP_REQUIRE((unsigned)act1 <= 4u && (unsigned)act2 <= 4u, VIP_ERR_BAD_ARG, "vip_se_gate_pooled_h2: unknown activation code");
+    VIP_REQUIRE(C % 8 == 0 && Cr % 8 == 0 && Cout % 8 == 0 && ldw1 % 16 == 0 && ldw2 % 16 == 0, VIP_ERR_ALIGNMENT,
+                "vip_se_gate_pooled_h2: C, Cr, Cout must be multiples of 8 elements, ldw1 / ldw2 of 16 halfs");
+    VIP_REQUIRE(ldw1 >= 2 * C && ldw2 >= 2 * Cr, VIP_ERR_BAD_ARG, "vip_se_gate_pooled_h2: leading dimension too small");
+    const size_t smem = ((size_t)C + C + Cr) * sizeof(float);
+    VIP_REQUIRE(smem <= 64 * 1024, VIP_ERR_UNSUPPORTED, "vip_se_gate_pooled_h2: C=%d too wide", C);
+    SeArgs a;
+    a.x = nullptr; a.w1 = (const f16*)w1; a.b1 = b1; a.w2 = (const f16*)w2; a.b2 = b2; a.gate = (f16*)gate;
+    a.HW = HW; a.C = C; a.ldx = C; a.Cr = Cr; a.ldw1 = ldw1; a.Co = Cout; a.ldw2 = ldw2; a.ldg = Cout;
+    a.act1 = act1; a.act2 = act2; a.split = 0;
+    a.part = partials; a.parts = parts;
+    a.s1 = s1; a.s2 = s2; a.status = status;
+    hipLaunchKernelGGL(se_gate_kernel<true>, dim3(B), dim3(SE_THREADS), smem, (hipStream_t)stream, a);
+    return vip_launch_status("vip_se_gate_pooled_h2");
+}
+
 extern "C" int vip_se_gate_pooled_f16(const float* partials, int parts, const void* w1, const float* b1, const void* w2,
                                       const float* b2, void* gate, int B, int HW, int C, int Cr, int ldw1, int Cout, int ldw2,
                                       int act1, int act2, int split, void* stream) {

@@ -872,6 +872,25 @@ def dwconv2d_se(x, w_khwc: torch.Tensor, bias: Optional[torch.Tensor], k: int, s
     pt, pb, pl, pr = pad
     Ho = (H + pt + pb - k) // stride + 1
     Wo = (W + pl + pr - k) // stride + 1
+    if (x.dtype == PACKED and _DW_SE_FUSED and _SE_H2_FUSED and not _UNFUSED and stride == 1 and _DW_H2_LDS and k >= _DW_H2_LDS
+            and fc1.kind == fc2.kind == "h2" and fc1.groups == fc2.groups == 1 and fc1.kh == fc1.kw == fc2.kh == fc2.kw == 1
+            and fc1.cin == Cc and fc2.cin == fc1.cout and Cc * fc1.cout + fc1.cout * fc2.cout <= 256 * 1024
+            and w_khwc.dtype == torch.float32 and w_khwc.is_contiguous() and w_khwc.shape == (k, k, Cc)):
+        # packed strict storage: the LDS-staged depthwise kernel leaves the pool's partial sums, the gate kernel finishes from them
+        parts = _abi.lib().vip_dwconv2d_s1_pool_parts_h2(B, H, W, Cc, k, Ho, Wo)
+        if parts > 0:
+            _chkp(x, "dwconv2d_se.x")
+            h = torch.empty((B, Ho, Wo, Cc), dtype=PACKED, device=x.device)
+            partials = torch.empty((B, parts, Cc), dtype=torch.float32, device=x.device)
+            st = _abi.lib().vip_dwconv2d_s1_pool_h2(_p(x), _p(_dw_quad_major(w_khwc, k)), _p(bias), _p(h), _p(partials), parts, B, H, W, Cc, k,
+                                                    pt, pl, Ho, Wo, _act(act), _p(h2_status()), _stream())
+            _abi.check(st, "vip_dwconv2d_s1_pool_h2")
+            gate = torch.empty((B, fc2.cout), dtype=PACKED, device=x.device)
+            st = _abi.lib().vip_se_gate_pooled_h2(_p(partials), parts, _p(fc1.w), _p(fc1.bias), 1.0 / fc1.h2_scale, _p(fc2.w), _p(fc2.bias),
+                                                  1.0 / fc2.h2_scale, _p(gate), B, Ho * Wo, Cc, fc1.cout, fc1.ldw, fc2.cout, fc2.ldw, _act(act1),
+                                                  _act(act2), _p(h2_status()), _stream())
+            _abi.check(st, "vip_se_gate_pooled_h2")
+            return h, gate
     fused = (_DW_SE_FUSED and not _UNFUSED and not _CALIB and not _EXACT and x.dtype == torch.float16 and stride == 1
              and fc1.cin == Cc and Cc * fc1.cout + fc1.cout * fc2.cout <= 256 * 1024
              and w_khwc.dtype == torch.float32 and w_khwc.is_contiguous() and w_khwc.shape == (k, k, Cc))
